@@ -97,7 +97,7 @@ def lib():
         _lib.orc_set_control.argtypes = [PP, fp, dp]
         _lib.orc_set_control.restype = C.c_int
         _lib.orc_adjacency.argtypes = [C.c_int, fp, C.c_double, fp]
-        _lib.orc_step.argtypes = [PP, C.c_int, C.c_int, dp, dp, dp, dp, C.c_void_p, fp, C.c_int, C.c_int, dp, C.c_int]
+        _lib.orc_step.argtypes = [PP, C.c_int, C.c_int, dp, dp, dp, dp, C.c_void_p, fp, C.c_int, C.c_int, dp, dp, C.c_int]
         _lib.orc_integrate.argtypes = [PP, dp, dp, dp, dp, dp, dp]
     return _lib
 
@@ -239,6 +239,7 @@ class OracleSwarm:
         self.angvel = np.zeros((self.E, self.N, 3))
         self.pid = new_pid(self.E * self.N)
         self.speeds = np.zeros((self.E, self.N, 4))
+        self.wrench = np.zeros((self.E, self.N, 6))
 
     def set_state(self, pos=None, euler=None, quat=None, vel=None, angvel=None):
         """Environment.set_state / Object.set_state semantics (None keeps the current value)."""
@@ -264,7 +265,7 @@ class OracleSwarm:
             a = f32(actions).reshape(self.E, self.N, adim)
             a_ptr = _f(a)
         lib().orc_step(C.byref(self.p), self.E, self.N, _d(self.pos), _d(self.quat), _d(self.vel), _d(self.angvel),
-                       self.pid.ctypes.data, a_ptr, at, adim, _d(self.speeds), int(self.nthreads))
+                       self.pid.ctypes.data, a_ptr, at, adim, _d(self.speeds), _d(self.wrench), int(self.nthreads))
 
     def observe(self):
         """float32 read-back of every agent: dict of (E,N,3) arrays + (E,N,3,3) mat."""

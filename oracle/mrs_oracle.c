@@ -440,8 +440,10 @@ void orc_adjacency(int n, const float *pos, double comm_range, float *A)
             float dx = pos[3 * i + 0] - pos[3 * j + 0];
             float dy = pos[3 * i + 1] - pos[3 * j + 1];
             float dz = pos[3 * i + 2] - pos[3 * j + 2];
-            float d2 = dx * dx + dy * dy;
-            d2 = d2 + dz * dz;
+            /* torch's float32 norm kernel contracts the sum of squares into FMAs on this host:
+             * d2 = fma(dz,dz, fma(dy,dy, dx*dx)); pinned bit-exactly by tests/golden/F3 (4096
+             * planted near-threshold pairs per range). */
+            float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             float d = sqrtf(d2);
             A[i * n + j] = (d <= cr) ? 1.f : 0.f;
         }
@@ -617,7 +619,7 @@ void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel
 
 static void step_env(const OrcParams *p, int N, double *pos, double *quat, double *vel, double *angvel,
                      OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out,
-                     double hclip)
+                     double *wrench_out, double hclip)
 {
     /* scratch on the stack in chunks is awkward for large N: use VLAs bounded by N */
     float opos[N][3], oeul[N][3], ovel[N][3], oang[N][3], omat[N][9];
@@ -722,12 +724,16 @@ static void step_env(const OrcParams *p, int N, double *pos, double *quat, doubl
             }
         }
     }
+    if (wrench_out)
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < 3; ++k) { wrench_out[6 * i + k] = fb[i][k]; wrench_out[6 * i + 3 + k] = tb[i][k]; }
     for (int i = 0; i < N; ++i) /* BulletSim.step_sim */
         orc_integrate(p, &pos[3 * i], &quat[4 * i], &vel[3 * i], &angvel[3 * i], fb[i], tb[i]);
 }
 
 void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, double *vel, double *angvel,
-              OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out, int nthreads)
+              OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out, double *wrench_out,
+              int nthreads)
 {
     double d[7];
     orc_derived(p, d);
@@ -738,7 +744,8 @@ void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, doubl
     for (int e = 0; e < E; ++e) {
         size_t o = (size_t)e * N;
         step_env(p, N, pos + 3 * o, quat + 4 * o, vel + 3 * o, angvel + 3 * o, pid + o,
-                 actions ? actions + o * adim : 0, action_type, adim, speeds_out ? speeds_out + 4 * o : 0, hclip);
+                 actions ? actions + o * adim : 0, action_type, adim, speeds_out ? speeds_out + 4 * o : 0,
+                 wrench_out ? wrench_out + 6 * o : 0, hclip);
     }
     (void)nthreads;
 }

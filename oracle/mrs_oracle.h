@@ -108,10 +108,12 @@ void orc_adjacency_batch(int E, int n, const float *pos, double comm_range, floa
 
 /* One env step for E envs x N agents (MRS.py:240-257 without the callbacks).
  * Arrays are [E][N][k] row-major.  actions may be NULL (ORC_ACT_NONE).
- * speeds_out (optional) receives the rotor speeds used this step, [E][N][4] double.
+ * speeds_out (optional) receives the rotor speeds used this step, [E][N][4] double;
+ * wrench_out (optional) the external body-frame wrench (force, torque) handed to the integrator, [E][N][6].
  * nthreads: OpenMP threads over envs (1 = scalar port). */
 void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, double *vel, double *angvel,
-              OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out, int nthreads);
+              OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out, double *wrench_out,
+              int nthreads);
 
 /* Pieces of orc_step, exposed so the reference's own Python can be driven on top of
  * them by tools/gen_golden.py (fake-bullet harness) and for unit tests. */

@@ -1,0 +1,154 @@
+"""The CPU oracle against the golden vectors captured from the reference's own Python
+(tools/gen_golden.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_derived_parameters():
+    # SURVEY.md 8a row P (Quadcopter.calculate_parameters, Quadcopter.py:153-168)
+    d = oracle.derived()
+    assert d["GravityForce"] == pytest.approx(0.26487, rel=1e-12)
+    assert d["HoverRPM"] == pytest.approx(14475.809, abs=1e-3)
+    assert d["MaxRPM"] == pytest.approx(21713.714, abs=1e-3)
+    assert d["MaxThrust"] == pytest.approx(0.5959575, rel=1e-9)
+    assert d["MaxXYTorque"] == pytest.approx(8.3649e-3, rel=1e-4)
+    assert d["MaxZTorque"] == pytest.approx(7.4872e-3, rel=1e-4)
+    assert d["GroundEffectHClip"] == pytest.approx(0.0377637, rel=1e-5)
+
+
+def test_survey_known_answers():
+    # SURVEY.md 8c anchors; inputs are python floats there, float32 here, hence the 1e-3 rpm slack
+    # on the values that depend on the float32 truncation of 0.01 / 0.1
+    c = oracle.Controller()
+    r = c.vel_control([0, 0, 0], [0, 0, 0], [0, 0, 0], [0.5, 0, 0])
+    np.testing.assert_allclose(r, [14214.56519004, 15073.76519004, 15073.76519004, 14214.56519004], atol=1e-6)
+    r = c.vel_control([0.01, 0, 0], [0, 0.01, 0], [0, 0.1, 0], [0.5, 0, 0])
+    np.testing.assert_allclose(r, [14110.11534986, 14969.31534986, 14969.31534986, 14110.11534986], atol=1e-3)
+    c = oracle.Controller()
+    r = c.pos_control([0, 0, 1], [0, 0, 0], [0, 0, 0.3], [0, 0, 0], [1, 1, 2])
+    np.testing.assert_allclose(r, [14728.22912486, 16041.00651222, 16446.62912486, 16041.00651222], atol=2e-3)
+    for args, want in [((0.027 * 9.81, 0, 0, 0), [14475.80915296] * 4),
+                       ((0.027, 1.4e-5, 0, 0), [4664.2590609, 4664.2590609, 4578.88702636, 4578.88702636]),
+                       ((0.027, 3e-3, 0, 0), [9211.17475125, 9211.17475125, 0, 0]),
+                       ((0.1, 0, -5e-3, 1e-4), [13972.41181714, 0, 0, 14269.7090935]),
+                       ((0, 1e-3, 1e-3, 0), [0, 6129.96615759, 0, 0])]:
+        np.testing.assert_allclose(oracle.nnls_rpm(*args)[0], want, atol=1e-6)
+
+
+def test_F1_quadcontrol_cascade():
+    d = np.load(os.path.join(G, "F1_quadcontrol.npz"))
+    for m, mode in enumerate([str(x) for x in d["modes"]]):
+        for i in range(d["rpm"].shape[1]):
+            c = oracle.Controller()
+            for k in range(d["rpm"].shape[2]):
+                a = {x: d[x][i, k] for x in ("pos", "vel", "ori", "angvel", "target")}
+                if mode == "pos":
+                    r = c.pos_control(a["pos"], a["vel"], a["ori"], a["angvel"], a["target"])
+                elif mode == "vel":
+                    r = c.vel_control(a["vel"], a["ori"], a["angvel"], a["target"])
+                elif mode == "accel":
+                    r = c.accel_control(a["target"].astype(np.float64), a["ori"], a["angvel"])
+                else:
+                    r = c.attitude_control((a["target"] * np.float32(0.3)).astype(np.float64), a["ori"], a["angvel"])
+                np.testing.assert_allclose(r, d["rpm"][m, i, k], rtol=0, atol=1e-8, err_msg="%s %d %d" % (mode, i, k))
+
+
+def test_F2_nnls_mixer():
+    d = np.load(os.path.join(G, "F2_nnls.npz"))
+    assert d["nnls_branch"].mean() > 0.3
+    for w, want in zip(d["wrench"], d["rpm"]):
+        np.testing.assert_allclose(oracle.nnls_rpm(*w)[0], want, rtol=0, atol=1e-8)
+
+
+def test_F3_adjacency_bit_exact():
+    d = np.load(os.path.join(G, "F3_adjacency.npz"))
+    n = 0
+    for k in d.files:
+        if k.endswith("_pos"):
+            key = k[:-4]
+            R = float(key.split("_R")[1].replace("p", "."))
+            A = oracle.adjacency(d[k], R).astype(np.uint8)
+            assert np.array_equal(A, d[key + "_A"]), key
+            n += 1
+        elif k.startswith("pairs") and k.endswith("_a"):
+            key = k[:-2]
+            R = float(key.split("_R")[1].replace("p", "."))
+            a, b = d[key + "_a"], d[key + "_b"]
+            pos = np.stack([a, b], 1)  # (P,2,3): each pair is its own 2-agent env
+            sw_A = np.zeros((len(a), 2, 2), np.float32)
+            oracle.lib().orc_adjacency_batch(len(a), 2, oracle._f(np.ascontiguousarray(pos)), R, oracle._f(sw_A))
+            assert np.array_equal(sw_A[:, 0, 1].astype(np.uint8), d[key + "_adj"]), key
+            assert 0.2 < d[key + "_adj"].mean() < 0.8   # the sweep really straddles the threshold
+            n += 1
+    assert n >= 30
+
+
+F6 = sorted(glob.glob(os.path.join(G, "F6_step_N*.npz")))
+
+
+def _swarm(d, N):
+    sw = oracle.OracleSwarm(1, N)
+    sw.set_state(pos=d["start"].astype(np.float64), euler=d["ori0"], vel=np.zeros((N, 3)), angvel=np.zeros((N, 3)))
+    return sw
+
+
+def _state(sw):
+    return np.concatenate([sw.pos[0], sw.quat[0], sw.vel[0], sw.angvel[0]], 1)
+
+
+@pytest.mark.parametrize("path", F6, ids=[os.path.basename(p)[8:-4] for p in F6])
+def test_F6_reference_step_teacher_forced(path):
+    """Each reference step reproduced from the reference's own previous state: force assembly
+    (controller -> rotor forces, ground effect, drag, downwash) and the observation/adjacency outputs."""
+    d = np.load(path)
+    name = os.path.basename(path)[8:-4]
+    N, atype = int(name.split("_")[0][1:]), name.split("_", 1)[1]
+    sw = _swarm(d, N)
+    K, D = int(d["K_HOPS"]), int(d["D"])
+    for t in range(d["actions"].shape[0]):
+        sw.step(d["actions"][t], atype)
+        w, wr = sw.wrench[0], d["wrench"][t]
+        scale = np.abs(wr[:, :3]).max(1, keepdims=True) + 1e-3
+        assert (np.abs(w[:, :3] - wr[:, :3]) / scale).max() < 2e-5, (t, "force")    # downwash is float32 in the reference
+        assert np.abs(w[:, 3:] - wr[:, 3:]).max() < 1e-9, (t, "torque")
+        assert np.abs(_state(sw) - d["state"][t]).max() < 2e-6, t
+        s = d["state"][t]
+        sw.pos[0], sw.quat[0], sw.vel[0], sw.angvel[0] = s[:, 0:3], s[:, 3:7], s[:, 7:10], s[:, 10:13]
+        # newest observation slice and adjacency from the (now identical) state
+        o = sw.observe()
+        X = np.concatenate([o["pos"][0], o["vel"][0]], 1) if D == 6 else \
+            np.concatenate([o["pos"][0], o["euler"][0], o["vel"][0], o["angvel"][0]], 1)
+        np.testing.assert_allclose(X, d["X"][t][0], rtol=0, atol=1e-6)
+        assert np.array_equal(sw.adjacency(float(d["COMM_RANGE"]))[0].astype(np.uint8), d["A"][t][0])
+
+
+@pytest.mark.parametrize("path", F6, ids=[os.path.basename(p)[8:-4] for p in F6])
+def test_F6_reference_step_free_running(path):
+    d = np.load(path)
+    name = os.path.basename(path)[8:-4]
+    N, atype = int(name.split("_")[0][1:]), name.split("_", 1)[1]
+    if name == "N12_set_control":
+        pytest.skip("tumbling + ground impacts: chaotic, covered by the teacher-forced test")
+    sw = _swarm(d, N)
+    worst = 0.0
+    for t in range(d["actions"].shape[0]):
+        sw.step(d["actions"][t], atype)
+        worst = max(worst, np.abs(_state(sw) - d["state"][t]).max())
+    assert worst < 1e-3, worst
+
+
+def test_F6_step_none_and_touchdown():
+    d = np.load(os.path.join(G, "F6_step_none_touchdown.npz"))
+    sw = _swarm(d, 3)
+    for t in range(d["state"].shape[0]):
+        sw.step(None, None)
+        assert np.abs(sw.wrench).max() == 0.0       # MRS.py:243-253: no set_actions => no rotor/aero forces
+        np.testing.assert_allclose(_state(sw), d["state"][t], rtol=0, atol=1e-9)
+    assert sw.pos[0, 0, 2] < 0.56 and abs(sw.vel[0, 0, 2]) < 0.05      # came to rest on the ground top (z = 0.5)

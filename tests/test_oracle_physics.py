@@ -1,0 +1,142 @@
+"""Analytic known-answer tests that pin the oracle's Bullet-style integrator independently of
+Bullet: the integrator restatement is otherwise "parity unpinned"."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as R
+
+import oracle
+
+
+def _p(**kw):
+    p = oracle.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_euler_quat_conventions_match_scipy():
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        e = rng.uniform(-1, 1, 3) * np.array([np.pi, np.pi / 2 * 0.98, np.pi])
+        q = oracle.euler_to_quat(e)
+        np.testing.assert_allclose(q, R.from_euler("xyz", e).as_quat(), atol=1e-14)
+        np.testing.assert_allclose(oracle.quat_to_matrix(q), R.from_quat(q).as_matrix(), atol=1e-14)
+        np.testing.assert_allclose(oracle.quat_to_euler(q), R.from_quat(q).as_euler("xyz"), atol=1e-11)
+
+
+def test_target_rotation_nearest_matches_scipy_from_matrix():
+    # QuadControl.py:82-89: non-orthonormal [x_t y_t z_t] -> from_matrix -> as_euler
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        Rb = R.from_euler("xyz", rng.uniform(-1, 1, 3)).as_matrix()
+        ta = rng.normal(size=3) * 3 + np.array([0, 0, 9.81])
+        tz = ta / np.linalg.norm(ta)
+        tx = np.cross(Rb[:, 1], tz)
+        ty = np.cross(tz, tx)
+        M = np.stack([tx, ty, tz], axis=1)
+        np.testing.assert_allclose(oracle.matrix_to_euler_nearest(M), R.from_matrix(M).as_euler("xyz"), atol=1e-11)
+
+
+def test_free_fall_recurrence_and_unit_quaternion():
+    p = _p(enable_contact=0)
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    sw.set_state(pos=[[0, 0, 50.0]], angvel=[[0.3, -0.2, 0.9]])
+    v, k, g, dt = 0.0, p.lin_damp, p.gravity, p.dt
+    z = 50.0
+    for _ in range(300):
+        sw.step(None, None)
+        v = v + dt * (-g - v * (k + k * abs(v)))      # ABA: F/m - v (k1 + k2 |v|)
+        z = z + dt * v                                # position uses the NEW velocity
+        assert sw.vel[0, 0, 2] == pytest.approx(v, abs=1e-12)
+        assert sw.pos[0, 0, 2] == pytest.approx(z, abs=1e-10)
+        assert np.linalg.norm(sw.quat[0, 0]) == pytest.approx(1.0, abs=1e-14)
+
+
+def test_spin_about_principal_axis_decays_by_damping_only():
+    p = _p(enable_contact=0, gravity=0.0)
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    sw.set_state(pos=[[0, 0, 5.0]], angvel=[[0, 0, 4.0]])
+    w = 4.0
+    for _ in range(200):
+        sw.step(None, None)
+        w = w + p.dt * (-(w * (p.ang_damp + p.ang_damp * abs(w))))
+        np.testing.assert_allclose(sw.angvel[0, 0], [0, 0, w], atol=1e-12)
+    yaw = oracle.quat_to_euler(sw.quat[0, 0])[2]
+    assert abs(yaw) > 0.1 and abs(oracle.quat_to_euler(sw.quat[0, 0])[0]) < 1e-12
+
+
+def test_kinetic_energy_monotone_without_forces():
+    p = _p(enable_contact=0, gravity=0.0)
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    sw.set_state(pos=[[0, 0, 5.0]], euler=np.array([[0.3, -0.4, 1.0]], np.float32), vel=[[1.0, -2.0, 0.5]],
+                 angvel=[[3.0, -5.0, 2.0]])
+    I = np.array(list(p.inertia))
+
+    def energy():
+        Rm = oracle.quat_to_matrix(sw.quat[0, 0])
+        wb = Rm.T @ sw.angvel[0, 0]
+        return 0.5 * p.mass * (sw.vel[0, 0] ** 2).sum() + 0.5 * (I * wb * wb).sum()
+
+    e0 = energy()
+    for _ in range(300):
+        sw.step(None, None)
+        e1 = energy()
+        assert e1 <= e0 * (1 + 1e-9)
+        e0 = e1
+
+
+def test_hover_force_balance_with_ground_effect():
+    p = _p(enable_contact=0)
+    d = oracle.derived(p)
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    h = 2.0
+    sw.set_state(pos=[[0, 0, h]])
+    rpm = np.full((1, 1, 4), d["HoverRPM"], np.float32)
+    sw.step(rpm, "set_speeds")
+    f32 = np.float32
+    thrust = 4 * float(f32(f32(rpm[0, 0, 0]) ** 2) * f32(p.kf))
+    gnd = 4 * float(f32(f32(f32(rpm[0, 0, 0]) ** 2) * f32(p.kf)) * f32(p.gnd_eff_coeff)) * (p.prop_radius / (4 * h)) ** 2
+    assert sw.wrench[0, 0, 2] == pytest.approx(thrust + gnd, rel=1e-12)
+    assert np.abs(sw.wrench[0, 0, [0, 1, 3, 4, 5]]).max() < 1e-18        # symmetric rotors: no lateral force / torque
+    assert sw.vel[0, 0, 2] == pytest.approx(p.dt * ((thrust + gnd) / p.mass - p.gravity), abs=1e-12)
+
+
+def test_rotor_torque_signs():
+    # cf2x.urdf:42-78 prop offsets; Quadcopter.py:42 yaw reaction -t0 + t1 - t2 + t3
+    p = _p(enable_contact=0)
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    sw.set_state(pos=[[0, 0, 2.0]])
+    a = np.array([[[16000, 14000, 14000, 14000]]], np.float32)
+    sw.step(a, "set_speeds")
+    tx, ty, tz = sw.wrench[0, 0, 3:]
+    assert tx > 0 and ty < 0 and tz < 0      # prop0 at (+x,+y): r x F = (+y F, -x F); spins "negative"
+
+
+def test_downwash_only_from_above():
+    p = _p(enable_contact=0)
+    sw = oracle.OracleSwarm(1, 2, params=p)
+    sw.set_state(pos=[[0, 0, 1.5], [0.02, 0.0, 2.5]])
+    hover = np.full((1, 2, 4), 14475.8, np.float32)
+    sw.step(hover, "set_speeds")
+    solo = oracle.OracleSwarm(1, 1, params=p)
+    solo.set_state(pos=[[0, 0, 1.5]])
+    solo.step(hover[:, :1], "set_speeds")
+    dz = 1.0
+    alpha = p.dw1 * (p.prop_radius / (4 * dz)) ** 2
+    beta = p.dw2 * dz + p.dw3
+    want = -alpha * np.exp(-0.5 * (0.02 / beta) ** 2)
+    assert sw.wrench[0, 0, 2] - solo.wrench[0, 0, 2] == pytest.approx(want, rel=1e-5)
+    solo2 = oracle.OracleSwarm(1, 1, params=p)
+    solo2.set_state(pos=[[0.02, 0, 2.5]])
+    solo2.step(hover[:, :1], "set_speeds")
+    assert sw.wrench[0, 1, 2] == solo2.wrench[0, 0, 2]        # the upper quad feels nothing
+
+
+def test_rest_on_ground_is_stable():
+    p = oracle.default_params()
+    sw = oracle.OracleSwarm(1, 1, params=p)
+    sw.set_state(pos=[[0, 0, p.ground_z + p.coll_half_len + 0.05]])
+    for _ in range(400):
+        sw.step(None, None)
+    assert sw.pos[0, 0, 2] == pytest.approx(p.ground_z + p.coll_half_len, abs=2e-3)
+    assert np.abs(sw.vel[0, 0]).max() < 1e-3 and np.abs(sw.angvel[0, 0]).max() < 1e-3
