@@ -1,0 +1,159 @@
+/*
+ * mrs_hip.h -- C-ABI of the MI355X-native mrsgym step()/reset() hot path.
+ *
+ * The reference (Acciorocketships/mrs-gym) has no FFI of its own: its lower boundary is the
+ * set of in-process pybullet C-API calls issued per agent per step.  This library replaces that
+ * boundary; each entry point names the reference interface (file:line under mrsgym/) it stands for.
+ *
+ *   plain pointers and sizes only; every buffer is DEVICE memory owned by the caller
+ *   (PyTorch allocates it); the library borrows it for the duration of the call, launches
+ *   asynchronously on the hipStream_t handed in as `void* stream`, never allocates or frees
+ *   user-visible memory, never throws.  Return value: 0 = ok, >0 = hipError_t, <0 = MRS_E_*.
+ *   A handle is bound to one device and is not thread-safe; distinct handles may be driven
+ *   from distinct threads/processes (one per GPU).
+ *
+ * Layout (agent-major SoA; a = env*N + agent, T = E*N): plane c of a k-component quantity
+ * lives at ptr[c*T + a], so that a wavefront's 64 lanes (64 consecutive quadcopters) read
+ * 64 consecutive words.
+ */
+#ifndef MRS_HIP_H
+#define MRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRS_ABI_VERSION 1
+
+/* error codes (negative) */
+#define MRS_E_ARG (-1)        /* bad argument (NULL, size, unsupported N) */
+#define MRS_E_ACTION_TYPE (-2)/* unknown ACTION_TYPE: the reference raises AttributeError (Environment.py:92) */
+#define MRS_E_NO_DEVICE (-3)
+
+/* ACTION_TYPE (Quadcopter.py:26-65). README.md:68 "set_force" has no implementation upstream. */
+#define MRS_ACT_NONE 0         /* step(None): MRS.py:243-253 */
+#define MRS_ACT_SET_SPEEDS 1   /* Quadcopter.set_speeds       :38-45  adim 4 */
+#define MRS_ACT_SET_CONTROL 2  /* Quadcopter.set_control      :26-34  adim 4 */
+#define MRS_ACT_TARGET_ACCEL 3 /* Quadcopter.set_target_accel :48-50  adim 3 */
+#define MRS_ACT_TARGET_VEL 4   /* Quadcopter.set_target_vel   :53-55  adim 3 */
+#define MRS_ACT_TARGET_POS 5   /* Quadcopter.set_target_pos   :58-60  adim 3 */
+#define MRS_ACT_TARGET_ORI 6   /* Quadcopter.set_target_ori   :63-65  adim 3 */
+
+/* observation fields a fused state_fn may concatenate (Object.get_pos/get_vel/get_ori/get_angvel,
+ * Object.py:78-97; all float32 as the reference's getters return them) */
+#define MRS_OBS_POS 0     /* 3 */
+#define MRS_OBS_VEL 1     /* 3 */
+#define MRS_OBS_EULER 2   /* 3  get_ori(): extrinsic 'xyz' roll,pitch,yaw */
+#define MRS_OBS_ANGVEL 3  /* 3  world frame */
+#define MRS_OBS_QUAT 4    /* 4  xyzw */
+#define MRS_OBS_MAX_FIELDS 8
+
+/* orientation encodings accepted by mrs_set_state (Object.set_state, Object.py:51-56) */
+#define MRS_ORI_EULER 0
+#define MRS_ORI_QUAT 1
+#define MRS_ORI_MATRIX 2
+
+/* status bits written to MrsBuffers.status[env] */
+#define MRS_STATUS_NAN_ACTION 1u /* MRS.py:247-248: the env's step was skipped, state untouched */
+#define MRS_STATUS_SPAWN_FAIL 2u /* rejection sampling hit its iteration bound (MRS.py:137-153 would spin forever) */
+
+/* Scene + model constants.  Filled by mrs_params_default from the values the
+ * reference parses out of cf2x.urdf / plane.urdf (Quadcopter.read_attributes, Quadcopter.py:119-150)
+ * and BulletSim.py:13-14; the [BULLET-KNOWLEDGE] block is re-pinnable at run time. */
+typedef struct MrsParams {
+    double mass, arm, kf, km, thrust2weight;
+    double ixx_file, iyy_file, izz_file;
+    double gnd_eff_coeff, prop_radius, drag_xy, drag_z, dw1, dw2, dw3;
+    double prop_x[4], prop_y[4], prop_z[4];
+    double coll_radius, coll_half_len;
+    double gravity, dt;             /* world (BulletSim kwargs GRAVITY, DT) */
+    double ctrl_gravity, ctrl_dt;   /* controller's frozen DefaultSim (Quadcopter.py:18, QuadControl.py:10) */
+    /* [BULLET-KNOWLEDGE] */
+    double inertia[3];
+    double lin_damp, ang_damp, max_coord_vel;
+    int32_t use_gyro;
+    int32_t enable_contact;
+    double ground_z, friction, erp, contact_threshold;
+    int32_t solver_iters;
+    int32_t reserved0;
+} MrsParams;
+
+/* Device buffers of one swarm shard (all borrowed).  Optional members may be NULL. */
+typedef struct MrsBuffers {
+    double *pos;      /* [3][T]  world position                                    */
+    double *quat;     /* [4][T]  body->world orientation, xyzw                     */
+    double *vel;      /* [3][T]  world linear velocity                             */
+    double *angvel;   /* [3][T]  world angular velocity                            */
+    double *pid64;    /* [12][T] integral_pos_e, d_vel_e, integral_vel_e, integral_ori_e (QuadControl.py:41-110) */
+    float *pid32;     /* [6][T]  last_vel_e, last_target_vel (NaN = attribute not created yet) */
+    float *obs;       /* (E,N,D) newest observation slice, row-major, or NULL      */
+    uint64_t *adj;    /* (E,N,W) bit-packed newest adjacency rows, W = ceil(N/64), or NULL */
+    float *rpm;       /* [4][T]  rotor speeds used by the last step (optional)     */
+    uint32_t *status; /* [E]     MRS_STATUS_* bits, OR-ed in (optional)            */
+} MrsBuffers;
+
+typedef struct MrsHandle MrsHandle;
+
+int mrs_abi_version(void);
+const char *mrs_last_error(void);
+
+/* cf2x + plane constants, Bullet defaults. */
+int mrs_params_default(MrsParams *out);
+/* Quadcopter.calculate_parameters (Quadcopter.py:153-168):
+ * GravityForce, HoverRPM, MaxRPM, MaxThrust, MaxXYTorque, MaxZTorque, GroundEffectHClip */
+int mrs_params_derived(const MrsParams *p, double out[7]);
+
+/* BulletSim.__init__/setup + env_generator('simple') (BulletSim.py:11-35, EnvCreator.py:7-13):
+ * binds a handle to `device` for E envs of N quadcopters over a ground box. */
+int mrs_create(const MrsParams *params, int n_envs, int n_agents, int device, MrsHandle **out);
+void mrs_destroy(MrsHandle *h);
+int mrs_set_params(MrsHandle *h, const MrsParams *params);
+
+/* bytes/words the caller must allocate for MrsBuffers members */
+int mrs_adj_words(int n_agents);               /* W */
+int mrs_obs_dim(const int32_t *fields, int n_fields); /* D, or <0 */
+
+/* QuadControl lazily-created attributes back to "not created" (a fresh Quadcopter, Quadcopter.py:14-19).
+ * env_mask: NULL = all envs, else E bytes (device), non-zero = apply. */
+int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream);
+
+/* Environment.set_state -> Object.set_state (Environment.py:97-103, Object.py:42-65).
+ * pos/vel/angvel: (E,N,3) float32 row-major device arrays or NULL = keep (MRS.set semantics);
+ * ori: (E,N,3) euler 'xyz' | (E,N,4) quat xyzw | (E,N,9) matrix, by ori_kind, or NULL = keep. */
+int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos, const float *ori, int ori_kind,
+                  const float *vel, const float *angvel, const uint8_t *env_mask, void *stream);
+/* float64 variant of the same (bit-exact state restore / sharding tests) */
+int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, const double *quat,
+                      const double *vel, const double *angvel, const uint8_t *env_mask, void *stream);
+
+/* MRS.step hot path (MRS.py:240-257): Environment.set_actions (controller -> rotor forces,
+ * Quadcopter.dynamics ground effect / drag / downwash), BulletSim.step_sim, then the newest
+ * observation slice (b->obs, fields as given) and the newest adjacency rows (b->adj, if
+ * comm_range is not NaN).  actions: (E,N,adim) float32 row-major, NULL only for MRS_ACT_NONE.
+ * comm_range = +inf reproduces MRS.py:118-119 (ones - eye). */
+int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
+             const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream);
+
+/* Environment.get_X fast path for a state_fn that concatenates getters (Environment.py:84-87),
+ * without stepping: used by reset()/set() -> calc_Xk (MRS.py:190, :203). */
+int mrs_observe(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs_fields, void *stream);
+
+/* MRS.calc_A (MRS.py:117-124) without stepping; writes b->adj. */
+int mrs_adjacency(MrsHandle *h, const MrsBuffers *b, double comm_range, void *stream);
+/* bit-packed rows -> the float32 0/1 matrices the reference returns: packed (M,N,W) -> dense (M,N,N) */
+int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int n_matrices, void *stream);
+
+/* MRS.generate_start_pos / generate_start_ori with the default spawn distribution
+ * (MRS.py:69-78, :127-161): xy ~ N(0,1) pulled into the unit disc, z ~ U[1,3], greedy re-sampling
+ * until all pairwise distances >= 2*agent_radius; yaw ~ U[ori_lo, ori_hi] per axis.
+ * Counter-based RNG keyed by (seed, global env index) so shards reproduce the single-GPU stream.
+ * Writes pos/quat, zeroes vel/angvel. */
+int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_index_base, double agent_radius,
+              const float ori_lo[3], const float ori_hi[3], int max_rounds, const uint8_t *env_mask, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

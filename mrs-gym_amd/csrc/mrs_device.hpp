@@ -1,0 +1,430 @@
+// mrs_device.hpp -- per-quadcopter device math of the fused step kernel (gfx950).
+//
+// One wavefront lane owns one quadcopter; everything here is straight-line register code with no
+// cross-lane traffic.  The arithmetic keeps the reference's precision split: values "read back"
+// from the simulator are truncated to float32 (Object.py:78-97) before the float64 controller math
+// (QuadControl.py), the downwash pair term is float32 (Quadcopter.py:99-115), the rigid-body state
+// itself is float64 like Bullet's.  Citations are file:line into the reference's mrsgym/ tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mrs_hip.h"
+
+#define MRS_DEV __device__ __forceinline__
+
+namespace mrs {
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct V3 {
+    double x, y, z;
+};
+struct M3 { // row-major rotation body->world
+    double m00, m01, m02, m10, m11, m12, m20, m21, m22;
+};
+
+MRS_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+MRS_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MRS_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MRS_DEV V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+MRS_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MRS_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+MRS_DEV double norm(V3 a) { return sqrt(dot(a, a)); }
+MRS_DEV V3 mul(const M3 &R, V3 v)
+{
+    return V3{R.m00 * v.x + R.m01 * v.y + R.m02 * v.z, R.m10 * v.x + R.m11 * v.y + R.m12 * v.z,
+              R.m20 * v.x + R.m21 * v.y + R.m22 * v.z};
+}
+MRS_DEV V3 mulT(const M3 &R, V3 v)
+{
+    return V3{R.m00 * v.x + R.m10 * v.y + R.m20 * v.z, R.m01 * v.x + R.m11 * v.y + R.m21 * v.z,
+              R.m02 * v.x + R.m12 * v.y + R.m22 * v.z};
+}
+MRS_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// scipy Rotation.as_matrix of the normalised quaternion (Object.py:93-95)
+MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
+{
+    const double n = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    const double x = qx / n, y = qy / n, z = qz / n, w = qw / n;
+    const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    M3 R;
+    R.m00 = x2 - y2 - z2 + w2; R.m01 = 2 * (xy - zw);      R.m02 = 2 * (xz + yw);
+    R.m10 = 2 * (xy + zw);      R.m11 = -x2 + y2 - z2 + w2; R.m12 = 2 * (yz - xw);
+    R.m20 = 2 * (xz - yw);      R.m21 = 2 * (yz + xw);      R.m22 = -x2 - y2 + z2 + w2;
+    return R;
+}
+
+// btMatrix3x3::setRotation (the matrix Bullet's integrator uses)
+MRS_DEV M3 quat_to_matrix_bullet(double qx, double qy, double qz, double qw)
+{
+    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
+    const double s = 2.0 / d;
+    const double xs = qx * s, ys = qy * s, zs = qz * s;
+    const double wx = qw * xs, wy = qw * ys, wz = qw * zs;
+    const double xx = qx * xs, xy = qx * ys, xz = qx * zs;
+    const double yy = qy * ys, yz = qy * zs, zz = qz * zs;
+    M3 R;
+    R.m00 = 1.0 - (yy + zz); R.m01 = xy - wz;         R.m02 = xz + wy;
+    R.m10 = xy + wz;         R.m11 = 1.0 - (xx + zz); R.m12 = yz - wx;
+    R.m20 = xz - wy;         R.m21 = yz + wx;         R.m22 = 1.0 - (xx + yy);
+    return R;
+}
+
+// as_euler('xyz') extrinsic: R = Rz(yaw) Ry(pitch) Rx(roll)  (Object.py:97)
+MRS_DEV void matrix_to_euler(const M3 &R, double &roll, double &pitch, double &yaw)
+{
+    double s = -R.m20;
+    s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
+    roll = atan2(R.m21, R.m22);
+    pitch = asin(s);
+    yaw = atan2(R.m10, R.m00);
+}
+
+// from_euler('xyz', e).as_matrix() (QuadControl.py:77, :99)
+MRS_DEV M3 euler_to_matrix(double roll, double pitch, double yaw)
+{
+    double sr, cr, sp, cp, sy, cy;
+    sincos(roll, &sr, &cr);
+    sincos(pitch, &sp, &cp);
+    sincos(yaw, &sy, &cy);
+    M3 R;
+    R.m00 = cy * cp; R.m01 = cy * sp * sr - sy * cr; R.m02 = cy * sp * cr + sy * sr;
+    R.m10 = sy * cp; R.m11 = sy * sp * sr + cy * cr; R.m12 = sy * sp * cr - cy * sr;
+    R.m20 = -sp;     R.m21 = cp * sr;                R.m22 = cp * cr;
+    return R;
+}
+
+// from_euler('xyz', e).as_quat()  (Object.py:54-56)
+MRS_DEV void euler_to_quat(double roll, double pitch, double yaw, double q[4])
+{
+    double sr, cr, sp, cp, sy, cy;
+    sincos(0.5 * roll, &sr, &cr);
+    sincos(0.5 * pitch, &sp, &cp);
+    sincos(0.5 * yaw, &sy, &cy);
+    q[0] = sr * cp * cy - cr * sp * sy;
+    q[1] = cr * sp * cy + sr * cp * sy;
+    q[2] = cr * cp * sy - sr * sp * cy;
+    q[3] = cr * cp * cy + sr * sp * sy;
+}
+
+// What the reference's getters hand to Python: float32 truncations (Object.py:78-97).
+struct Observed {
+    float px, py, pz, vx, vy, vz, wx, wy, wz;
+    float roll, pitch, yaw;
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22; // get_ori(mat=True)
+};
+
+template <bool WANT_EULER, bool WANT_MAT>
+MRS_DEV void observe(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o)
+{
+    o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
+    o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
+    o.wx = (float)w[0]; o.wy = (float)w[1]; o.wz = (float)w[2];
+    if (WANT_EULER || WANT_MAT) {
+        // quat = torch.tensor(state[1]) is float32 BEFORE scipy normalises it (Object.py:92-93)
+        const M3 R = quat_to_matrix_scipy((double)(float)q[0], (double)(float)q[1], (double)(float)q[2], (double)(float)q[3]);
+        if (WANT_EULER) {
+            double r, pt, y;
+            matrix_to_euler(R, r, pt, y);
+            o.roll = (float)r; o.pitch = (float)pt; o.yaw = (float)y;
+        }
+        if (WANT_MAT) {
+            o.r00 = (float)R.m00; o.r01 = (float)R.m01; o.r02 = (float)R.m02;
+            o.r10 = (float)R.m10; o.r11 = (float)R.m11; o.r12 = (float)R.m12;
+            o.r20 = (float)R.m20; o.r21 = (float)R.m21; o.r22 = (float)R.m22;
+        }
+    }
+}
+
+// Controller memory of one quadcopter, in registers for the duration of a step.
+struct Pid {
+    double ipx, ipy, ipz; // integral_pos_e   QuadControl.py:41-44
+    double dvx, dvy, dvz; // d_vel_e          :57,:62
+    double ivx, ivy, ivz; // integral_vel_e   :60-61,:66
+    double iox, ioy, ioz; // integral_ori_e   :105,:108-110
+    float lvx, lvy, lvz;  // last_vel_e       :56,:64   NaN = not created
+    float ltx, lty, ltz;  // last_target_vel  :58-59,:65
+};
+
+// QuadControl.attitude_control (QuadControl.py:93-127).  Rt is the target rotation matrix.
+MRS_DEV void attitude_control(const MrsParams &P, Pid &s, const M3 &Rt, const M3 &R, const Observed &o, V3 ta,
+                              double rpm[4])
+{
+    // E = Rt^T R - R^T Rt ; rot_e = (E21, E02, E10)   (:101-102)
+    const double a21 = Rt.m02 * R.m01 + Rt.m12 * R.m11 + Rt.m22 * R.m21;
+    const double a12 = Rt.m01 * R.m02 + Rt.m11 * R.m12 + Rt.m21 * R.m22;
+    const double a02 = Rt.m00 * R.m02 + Rt.m10 * R.m12 + Rt.m20 * R.m22;
+    const double a20 = Rt.m02 * R.m00 + Rt.m12 * R.m10 + Rt.m22 * R.m20;
+    const double a10 = Rt.m01 * R.m00 + Rt.m11 * R.m10 + Rt.m21 * R.m20;
+    const double a01 = Rt.m00 * R.m01 + Rt.m10 * R.m11 + Rt.m20 * R.m21;
+    const double ex = a21 - a12, ey = a02 - a20, ez = a10 - a01;
+    const double dt = P.ctrl_dt;
+    s.iox = clampd(clampd(s.iox - ex * dt, -1500., 1500.), -1., 1.); // :108-110
+    s.ioy = clampd(clampd(s.ioy - ey * dt, -1500., 1500.), -1., 1.);
+    s.ioz = clampd(s.ioz - ez * dt, -1500., 1500.);
+    // :112-115  P=(7e4,7e4,6e4) I=(0,0,500) D=(2e4,2e4,1.2e4), angvel_e = 0 - angvel
+    const double tx = clampd(-(70000. * ex) + 0. * s.iox + 20000. * (0.0 - (double)o.wx), -3200., 3200.);
+    const double ty = clampd(-(70000. * ey) + 0. * s.ioy + 20000. * (0.0 - (double)o.wy), -3200., 3200.);
+    const double tz = clampd(-(60000. * ez) + 500. * s.ioz + 12000. * (0.0 - (double)o.wz), -3200., 3200.);
+    const double nta = norm(ta);
+    double thrust = 0.;
+    if (nta != 0) { // :117-122
+        const double cosang = (ta.x / nta) * R.m02 + (ta.y / nta) * R.m12 + (ta.z / nta) * R.m22;
+        thrust = (1 / (cosang > 0.2 ? cosang : 0.2)) * nta * P.mass;
+    }
+    const double tp = (sqrt(thrust / (4 * P.kf)) - 4070.3) / 0.2685; // :123
+    // MixerMatrix (:27) rows (.5,-.5,-1) (.5,.5,1) (-.5,.5,-1) (-.5,-.5,1); clip [20000,65535]; rpm = .2685 pwm + 4070.3
+    rpm[0] = 0.2685 * clampd(tp + (.5 * tx - .5 * ty - tz), 20000., 65535.) + 4070.3;
+    rpm[1] = 0.2685 * clampd(tp + (.5 * tx + .5 * ty + tz), 20000., 65535.) + 4070.3;
+    rpm[2] = 0.2685 * clampd(tp + (-.5 * tx + .5 * ty - tz), 20000., 65535.) + 4070.3;
+    rpm[3] = 0.2685 * clampd(tp + (-.5 * tx - .5 * ty + tz), 20000., 65535.) + 4070.3;
+}
+
+// QuadControl.accel_control (QuadControl.py:73-90).  `R` = from_euler(ori float32) in float64.
+MRS_DEV void accel_control(const MrsParams &P, Pid &s, V3 ta_in, const M3 &R, const Observed &o, double rpm[4])
+{
+    const V3 ta = v3(ta_in.x + 0., ta_in.y + 0., ta_in.z + P.ctrl_gravity); // :76
+    const double n = norm(ta);
+    V3 tz = v3(ta.x / n, ta.y / n, ta.z / n); // :78
+    if (isnan(tz.x) || isnan(tz.y) || isnan(tz.z)) tz = v3(0., 0., 1.); // :79-80
+    // :77 rotation is cast to float32; :82 x_t = R[:,1] x z_t (not normalised); :83 y_t = z_t x x_t
+    const V3 ycol = v3((double)(float)R.m01, (double)(float)R.m11, (double)(float)R.m21);
+    const V3 tx = cross(ycol, tz);
+    const V3 ty = cross(tz, tx);
+    // :88-89 from_matrix() of the non-orthonormal [x_t y_t z_t] = nearest rotation = column
+    // normalisation (columns are mutually orthogonal); :100 rebuilds the same matrix from its euler angles.
+    const double nx = 1.0 / norm(tx), ny = 1.0 / norm(ty), nz = 1.0 / norm(tz);
+    M3 Rt;
+    Rt.m00 = tx.x * nx; Rt.m10 = tx.y * nx; Rt.m20 = tx.z * nx;
+    Rt.m01 = ty.x * ny; Rt.m11 = ty.y * ny; Rt.m21 = ty.z * ny;
+    Rt.m02 = tz.x * nz; Rt.m12 = tz.y * nz; Rt.m22 = tz.z * nz;
+    attitude_control(P, s, Rt, R, o, ta, rpm);
+}
+
+// QuadControl.vel_control (QuadControl.py:51-70): vel_e and the derivative numerator are float32 arithmetic
+MRS_DEV V3 vel_control_accel(const MrsParams &P, Pid &s, const Observed &o, float tvx, float tvy, float tvz)
+{
+    const float dt32 = (float)P.ctrl_dt;
+    const float ex = __fsub_rn(tvx, o.vx), ey = __fsub_rn(tvy, o.vy), ez = __fsub_rn(tvz, o.vz); // :54
+    if (isnan(s.lvx)) { s.lvx = ex; s.lvy = ey; s.lvz = ez; s.dvx = s.dvy = s.dvz = 0.; }       // :55-57
+    if (isnan(s.ltx)) { s.ltx = tvx; s.lty = tvy; s.ltz = tvz; }                                // :58-59
+    // :62 d = (((e - e_last) - (tv - tv_last)) / DT) * 0.5 + d * 0.5
+    const float hx = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ex, s.lvx), __fsub_rn(tvx, s.ltx)), dt32), 0.5f);
+    const float hy = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ey, s.lvy), __fsub_rn(tvy, s.lty)), dt32), 0.5f);
+    const float hz = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ez, s.lvz), __fsub_rn(tvz, s.ltz)), dt32), 0.5f);
+    s.dvx = (double)hx + s.dvx * 0.5; s.dvy = (double)hy + s.dvy * 0.5; s.dvz = (double)hz + s.dvz * 0.5;
+    s.lvx = ex; s.lvy = ey; s.lvz = ez;       // :64
+    s.ltx = tvx; s.lty = tvy; s.ltz = tvz;    // :65
+    s.ivx = s.ivx + (double)__fmul_rn(ex, dt32); // :66
+    s.ivy = s.ivy + (double)__fmul_rn(ey, dt32);
+    s.ivz = s.ivz + (double)__fmul_rn(ez, dt32);
+    // :67-69 P=3 I=.1 D=1
+    return v3(3. * (double)ex + .1 * s.ivx + 1. * s.dvx, 3. * (double)ey + .1 * s.ivy + 1. * s.dvy,
+              3. * (double)ez + .1 * s.ivz + 1. * s.dvz);
+}
+
+// QuadControl.pos_control (QuadControl.py:35-48)
+MRS_DEV V3 pos_control_accel(const MrsParams &P, Pid &s, const Observed &o, float tpx, float tpy, float tpz)
+{
+    const float dt32 = (float)P.ctrl_dt;
+    const float ex = __fsub_rn(tpx, o.px), ey = __fsub_rn(tpy, o.py), ez = __fsub_rn(tpz, o.pz); // :40
+    s.ipx = s.ipx + (double)__fmul_rn(ex, dt32); // :44
+    s.ipy = s.ipy + (double)__fmul_rn(ey, dt32);
+    s.ipz = s.ipz + (double)__fmul_rn(ez, dt32);
+    // :45-47 P=1.5 I=.001 D=1 with d_pos_e = 0 - vel
+    return v3(1.5 * (double)ex + .001 * s.ipx + 1. * (0.0 - (double)o.vx),
+              1.5 * (double)ey + .001 * s.ipy + 1. * (0.0 - (double)o.vy),
+              1.5 * (double)ez + .001 * s.ipz + 1. * (0.0 - (double)o.vz));
+}
+
+// 2-variable NNLS of the normal-equation block [[3,1],[1,3]] [x y]^T = [p q]^T, exact KKT enumeration
+MRS_DEV void nnls2(double p, double q, double &x, double &y)
+{
+    const double xs = (3. * p - q) * 0.125, ys = (3. * q - p) * 0.125;
+    if (xs >= 0. && ys >= 0.) { x = xs; y = ys; return; }
+    const double y0 = q / 3., x0 = p / 3.;
+    if (y0 >= 0. && p - y0 <= 0.) { x = 0.; y = y0; return; }
+    if (x0 >= 0. && q - x0 <= 0.) { x = x0; y = 0.; return; }
+    x = 0.; y = 0.;
+}
+
+// Quadcopter.set_control + nnlsRPM (Quadcopter.py:26-34, :172-208).  The mixer matrix A (:164)
+// has A^T A = [[3,0,1,0],[0,3,0,1],[1,0,3,0],[0,1,0,3]]: the 4-variable NNLS the reference hands to
+// scipy splits into two independent 2-variable problems {0,2} and {1,3}, solved in closed form.
+MRS_DEV void set_control(const MrsParams &P, float c0, float c1, float c2, float c3, double rpm[4])
+{
+    const double thrust = (double)__fmul_rn(c0, (float)P.mass);   // :27-30 float32 tensor * python float
+    const double roll = (double)__fmul_rn(c1, (float)P.ixx_file);
+    const double pitch = (double)__fmul_rn(c2, (float)P.iyy_file);
+    const double yaw = (double)__fmul_rn(c3, (float)P.izz_file);
+    const double c = 0.70710678118654752440;
+    const double B0 = thrust * (1 / P.kf), B1 = roll * (1 / (P.kf * P.arm)), B2 = pitch * (1 / (P.kf * P.arm)),
+                 B3 = yaw * (1 / P.km); // :166, :202
+    // sq = Ainv B with Ainv = A^T diag(1/4,1/2,1/2,1/4)
+    double s0 = 0.25 * B0 + (0.5 * c) * B1 - (0.5 * c) * B2 - 0.25 * B3;
+    double s1 = 0.25 * B0 + (0.5 * c) * B1 + (0.5 * c) * B2 + 0.25 * B3;
+    double s2 = 0.25 * B0 - (0.5 * c) * B1 + (0.5 * c) * B2 - 0.25 * B3;
+    double s3 = 0.25 * B0 - (0.5 * c) * B1 - (0.5 * c) * B2 + 0.25 * B3;
+    if (fmin(fmin(s0, s1), fmin(s2, s3)) < 0) { // :204-207
+        const double b0 = B0 + c * B1 - c * B2 - B3; // A^T B
+        const double b1 = B0 + c * B1 + c * B2 + B3;
+        const double b2 = B0 - c * B1 + c * B2 - B3;
+        const double b3 = B0 - c * B1 - c * B2 + B3;
+        nnls2(b0, b2, s0, s2);
+        nnls2(b1, b3, s1, s3);
+    }
+    rpm[0] = sqrt(s0); rpm[1] = sqrt(s1); rpm[2] = sqrt(s2); rpm[3] = sqrt(s3); // :208
+}
+
+// One downwash pair term in the reference's float32 arithmetic (Quadcopter.py:103-110);
+// (rx,ry,dz) = other - self.
+MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
+{
+    const float dxy = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry))); // np.linalg.norm(rel[:2])
+    float f = 0.f;
+    if (dz > 0.f && dxy < 10.f) {
+        const float rc = __fdiv_rn(1.0f, __fmul_rn(4.0f, dz));   // PropRadius/(4 dz) = reciprocal()*scalar
+        const float q = __fmul_rn(rc, pr32);
+        const float alpha = __fmul_rn(dw1, __fmul_rn(q, q));
+        const float beta = __fadd_rn(__fmul_rn(dw2, dz), dw3);
+        const float t = __fmul_rn(__fdiv_rn(1.0f, beta), dxy);   // np.float32 / tensor -> reciprocal()*other
+        const float ex = expf(__fmul_rn(-.5f, __fmul_rn(t, t)));
+        f = -__fmul_rn(alpha, ex);
+    }
+    return f;
+}
+
+// Ground contact, the build's own model (DESIGN.md "Row G"): 8 body-fixed rim points of the collision
+// cylinder against z = ground_z, Bullet-style velocity-level rhs, sequential impulses with a friction
+// pyramid along world x/y.  Mirrors oracle/mrs_oracle.c:contact_solve operation for operation.
+struct ContactPoint {
+    double rx, ry, rz;
+};
+
+MRS_DEV V3 apply_inv_inertia_world(const M3 &R, const double Iinv[3], V3 t)
+{
+    V3 b = mulT(R, t);
+    b.x *= Iinv[0]; b.y *= Iinv[1]; b.z *= Iinv[2];
+    return mul(R, b);
+}
+
+__device__ __noinline__ void contact_solve(const MrsParams &P, const double pos[3], const M3 &R, double v[3], double w[3])
+{
+    const double c = P.coll_radius * 0.70710678118654752440;
+    const double Iinv[3] = {1.0 / P.inertia[0], 1.0 / P.inertia[1], 1.0 / P.inertia[2]};
+    double lam_n[8], lam_t0[8], lam_t1[8];
+    unsigned active = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const V3 pb = v3((k & 1) ? -c : c, (k & 2) ? -c : c, (k & 4) ? -P.coll_half_len : P.coll_half_len);
+        const V3 r = mul(R, pb);
+        const double dist = pos[2] + r.z - P.ground_z;
+        if (dist <= P.contact_threshold) active |= 1u << k;
+        lam_n[k] = 0.; lam_t0[k] = 0.; lam_t1[k] = 0.;
+    }
+    if (!active) return;
+    const double v0x = v[0], v0y = v[1], v0z = v[2], w0x = w[0], w0y = w[1], w0z = w[2];
+    (void)v0x; (void)v0y; (void)w0z;
+    for (int it = 0; it < P.solver_iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!(active & (1u << k))) continue;
+            const V3 pb = v3((k & 1) ? -c : c, (k & 2) ? -c : c, (k & 4) ? -P.coll_half_len : P.coll_half_len);
+            const V3 r = mul(R, pb);
+            const double dist = pos[2] + r.z - P.ground_z;
+            // effective masses for z, x, y
+            double K[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const V3 d = v3(a == 1 ? 1. : 0., a == 2 ? 1. : 0., a == 0 ? 1. : 0.);
+                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, d));
+                const V3 cr = cross(tw, r);
+                K[a] = 1.0 / (1.0 / P.mass + dot(d, cr));
+            }
+            // rhs from the unconstrained velocities (v0,w0)
+            const double vrel_n0 = v0z + (w0x * r.y - w0y * r.x);
+            double poserr = 0., velerr = -vrel_n0;
+            if (dist > 0) velerr -= dist / P.dt; else poserr = -dist * P.erp / P.dt;
+            const double rhs = poserr + velerr;
+            { // normal
+                const double dvn = (v[2] - v0z) + ((w[0] - w0x) * r.y - (w[1] - w0y) * r.x);
+                double nl = lam_n[k] + K[0] * (rhs - dvn);
+                if (nl < 0) nl = 0;
+                const double dl = nl - lam_n[k];
+                lam_n[k] = nl;
+                v[2] += dl / P.mass;
+                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, v3(0., 0., dl)));
+                w[0] += tw.x; w[1] += tw.y; w[2] += tw.z;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { // friction x, y
+                const V3 d = v3(a == 0 ? 1. : 0., a == 1 ? 1. : 0., 0.);
+                const V3 wxr = cross(v3(w[0], w[1], w[2]), r);
+                const double vt = d.x * (v[0] + wxr.x) + d.y * (v[1] + wxr.y);
+                const double lim = P.friction * lam_n[k];
+                double &lt = a == 0 ? lam_t0[k] : lam_t1[k];
+                const double nl = clampd(lt + (-K[1 + a] * vt), -lim, lim);
+                const double dl = nl - lt;
+                lt = nl;
+                v[0] += d.x * dl / P.mass; v[1] += d.y * dl / P.mass;
+                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, v3(d.x * dl, d.y * dl, 0.)));
+                w[0] += tw.x; w[1] += tw.y; w[2] += tw.z;
+            }
+        }
+    }
+}
+
+// BulletSim.step_sim -> stepSimulation (BulletSim.py:46-47).  [BULLET-KNOWLEDGE] btMultiBody ABA for a
+// floating base with massless fixed links, applyDeltaVeeMultiDof (+-max_coord_vel clamp), contact,
+// stepPositionsMultiDof (exponential map with Taylor branch and angular-motion threshold).
+MRS_DEV void integrate(const MrsParams &P, double p[3], double q[4], double v[3], double w[3], V3 fb_ext, V3 tb_ext)
+{
+    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+    const V3 vb = mulT(R, v3(v[0], v[1], v[2]));
+    const V3 wb = mulT(R, v3(w[0], w[1], w[2]));
+    const V3 gb = mulT(R, v3(0., 0., -P.gravity * P.mass));
+    const V3 fb = fb_ext + gb;
+    const double nv = norm(vb), nw = norm(wb);
+    const V3 Iw = v3(P.inertia[0] * wb.x, P.inertia[1] * wb.y, P.inertia[2] * wb.z);
+    const V3 gyro = P.use_gyro ? cross(wb, Iw) : v3(0., 0., 0.);
+    const V3 cor = cross(wb, vb);
+    const double kl = P.lin_damp, ka = P.ang_damp;
+    // zeroAccSpatFrc = -F + damping + coriolis ; acc = -zeroAcc / inertia
+    const V3 ab = v3(-(-fb.x + P.mass * vb.x * (kl + kl * nv) + P.mass * cor.x) / P.mass,
+                     -(-fb.y + P.mass * vb.y * (kl + kl * nv) + P.mass * cor.y) / P.mass,
+                     -(-fb.z + P.mass * vb.z * (kl + kl * nv) + P.mass * cor.z) / P.mass);
+    const V3 alb = v3(-(-tb_ext.x + Iw.x * (ka + ka * nw) + gyro.x) / P.inertia[0],
+                      -(-tb_ext.y + Iw.y * (ka + ka * nw) + gyro.y) / P.inertia[1],
+                      -(-tb_ext.z + Iw.z * (ka + ka * nw) + gyro.z) / P.inertia[2]);
+    const V3 vdot = mul(R, ab + cor);
+    const V3 wdot = mul(R, alb);
+    const double dt = P.dt, mv = P.max_coord_vel;
+    w[0] = clampd(w[0] + wdot.x * dt, -mv, mv); w[1] = clampd(w[1] + wdot.y * dt, -mv, mv); w[2] = clampd(w[2] + wdot.z * dt, -mv, mv);
+    v[0] = clampd(v[0] + vdot.x * dt, -mv, mv); v[1] = clampd(v[1] + vdot.y * dt, -mv, mv); v[2] = clampd(v[2] + vdot.z * dt, -mv, mv);
+    if (P.enable_contact) {
+        const double bound = sqrt(P.coll_radius * P.coll_radius + P.coll_half_len * P.coll_half_len);
+        if (!(p[2] - bound - P.contact_threshold > P.ground_z)) contact_solve(P, p, R, v, w);
+    }
+    p[0] += dt * v[0]; p[1] += dt * v[1]; p[2] += dt * v[2];
+    double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (fAngle * dt > 0.25 * kPi) fAngle = 0.5 * (0.5 * kPi) / dt;
+    double sc;
+    if (fAngle < 0.001)
+        sc = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle;
+    else
+        sc = sin(0.5 * fAngle * dt) / fAngle;
+    const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc, dw = cos(fAngle * dt * 0.5);
+    const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const double nx = dw * qx + ax * qw + ay * qz - az * qy;
+    const double ny = dw * qy + ay * qw + az * qx - ax * qz;
+    const double nz = dw * qz + az * qw + ax * qy - ay * qx;
+    const double nw2 = dw * qw - ax * qx - ay * qy - az * qz;
+    const double nn = sqrt(nx * nx + ny * ny + nz * nz + nw2 * nw2);
+    q[0] = nx / nn; q[1] = ny / nn; q[2] = nz / nn; q[3] = nw2 / nn;
+}
+
+} // namespace mrs

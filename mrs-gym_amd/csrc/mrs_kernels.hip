@@ -1,0 +1,736 @@
+// mrs_kernels.hip -- gfx950 kernels + C-ABI host entry points (include/mrs_hip.h).
+//
+// Mapping: one wavefront lane per quadcopter, agent-major.  A 256-thread workgroup owns
+// floor(256/N) whole envs (N=64: 4 envs, one wave each; N=256: one env over 4 waves); N in
+// (256,1024] takes one env per workgroup of roundup64(N) threads.  The env's float32 positions are
+// staged once in LDS and serve both O(N^2) loops (pre-step: downwash, Quadcopter.py:99-115;
+// post-step: COMM_RANGE adjacency, MRS.py:117-124) as conflict-free broadcast reads.
+// Nothing here is a dense contraction: MFMA is deliberately unused; the kernel streams the SoA
+// state planes once in and once out per step.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mrs_device.hpp"
+
+using namespace mrs;
+
+// ------------------------------------------------------------------------------------------ args
+struct StepArgs {
+    MrsParams P;
+    MrsBuffers b;
+    const float *actions;
+    const uint8_t *mask;
+    int E, N, T, epb;
+    int n_obs, D;
+    int obs_fields[MRS_OBS_MAX_FIELDS];
+    int do_adj, comm_inf, W;
+    float d2_thresh;
+    double hclip;
+};
+
+__device__ __forceinline__ void load_state(const MrsBuffers &b, size_t a, size_t T, double p[3], double q[4], double v[3], double w[3])
+{
+    p[0] = b.pos[a]; p[1] = b.pos[T + a]; p[2] = b.pos[2 * T + a];
+    q[0] = b.quat[a]; q[1] = b.quat[T + a]; q[2] = b.quat[2 * T + a]; q[3] = b.quat[3 * T + a];
+    v[0] = b.vel[a]; v[1] = b.vel[T + a]; v[2] = b.vel[2 * T + a];
+    w[0] = b.angvel[a]; w[1] = b.angvel[T + a]; w[2] = b.angvel[2 * T + a];
+}
+__device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_t T, const double p[3], const double q[4], const double v[3], const double w[3])
+{
+    b.pos[a] = p[0]; b.pos[T + a] = p[1]; b.pos[2 * T + a] = p[2];
+    b.quat[a] = q[0]; b.quat[T + a] = q[1]; b.quat[2 * T + a] = q[2]; b.quat[3 * T + a] = q[3];
+    b.vel[a] = v[0]; b.vel[T + a] = v[1]; b.vel[2 * T + a] = v[2];
+    b.angvel[a] = w[0]; b.angvel[T + a] = w[1]; b.angvel[2 * T + a] = w[2];
+}
+
+// newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
+__device__ __forceinline__ void write_obs(const StepArgs &A, size_t a, const double p[3], const double q[4], const double v[3], const double w[3])
+{
+    float *o = A.b.obs + a * (size_t)A.D;
+    bool want_euler = false;
+    for (int f = 0; f < A.n_obs; ++f) want_euler |= (A.obs_fields[f] == MRS_OBS_EULER);
+    Observed ob;
+    if (want_euler) observe<true, false>(p, q, v, w, ob); else observe<false, false>(p, q, v, w, ob);
+    int off = 0;
+    for (int f = 0; f < A.n_obs; ++f) {
+        switch (A.obs_fields[f]) {
+        case MRS_OBS_POS: o[off] = ob.px; o[off + 1] = ob.py; o[off + 2] = ob.pz; off += 3; break;
+        case MRS_OBS_VEL: o[off] = ob.vx; o[off + 1] = ob.vy; o[off + 2] = ob.vz; off += 3; break;
+        case MRS_OBS_EULER: o[off] = ob.roll; o[off + 1] = ob.pitch; o[off + 2] = ob.yaw; off += 3; break;
+        case MRS_OBS_ANGVEL: o[off] = ob.wx; o[off + 1] = ob.wy; o[off + 2] = ob.wz; off += 3; break;
+        case MRS_OBS_QUAT: o[off] = (float)q[0]; o[off + 1] = (float)q[1]; o[off + 2] = (float)q[2]; o[off + 3] = (float)q[3]; off += 4; break;
+        default: break;
+        }
+    }
+}
+
+// bit-packed adjacency row of agent i from the env's LDS position tile (MRS.calc_A, MRS.py:117-124):
+// float32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it, sqrt(d2) <= R
+// folded into d2 <= d2_thresh (largest float whose correctly rounded sqrt is <= R; host-computed).
+__device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *tile_env, int i, float4 me, uint64_t *row)
+{
+    for (int wd = 0; wd < A.W; ++wd) {
+        uint64_t bits = 0;
+        const int jn = min(64, A.N - wd * 64);
+        for (int jj = 0; jj < jn; ++jj) {
+            const int j = wd * 64 + jj;
+            const float4 pj = tile_env[j];
+            const float dx = __fsub_rn(me.x, pj.x), dy = __fsub_rn(me.y, pj.y), dz = __fsub_rn(me.z, pj.z);
+            const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+            const bool adj = (A.comm_inf ? true : (d2 <= A.d2_thresh)) && (j != i);
+            bits |= (uint64_t)adj << jj;
+        }
+        row[wd] = bits;
+    }
+}
+
+// ------------------------------------------------------------------------------------ step kernel
+template <int ACT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
+{
+    extern __shared__ float4 lds_tile[]; // BLOCK positions, then one int flag per env slot
+    int *nanflag = reinterpret_cast<int *>(lds_tile + BLOCK);
+
+    const int tid = threadIdx.x;
+    const int el = tid / A.N;
+    const int i = tid - el * A.N;
+    const int e = blockIdx.x * A.epb + el;
+    const bool live = (el < A.epb) && (e < A.E);
+    const size_t T = (size_t)A.T;
+    const size_t a = live ? (size_t)e * A.N + i : 0;
+    constexpr int ADIM = (ACT == MRS_ACT_SET_SPEEDS || ACT == MRS_ACT_SET_CONTROL) ? 4 : 3;
+
+    double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+    float act[4] = {0, 0, 0, 0};
+    if (tid < A.epb) nanflag[tid] = 0;
+    if (live) {
+        load_state(A.b, a, T, p, q, v, w);
+        if (ACT != MRS_ACT_NONE) {
+#pragma unroll
+            for (int k = 0; k < ADIM; ++k) act[k] = A.actions[a * ADIM + k];
+        }
+    }
+    lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    __syncthreads();
+    if (live && ACT != MRS_ACT_NONE) {
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < ADIM; ++k) bad |= isnan(act[k]);
+        if (bad) nanflag[el] = 1; // MRS.py:247-248: any NaN in the env's action aborts that env's step
+    }
+    __syncthreads();
+    const bool masked = live && A.mask && !A.mask[e];
+    const bool doit = live && !masked && !(ACT != MRS_ACT_NONE && nanflag[el]);
+    if (live && i == 0 && ACT != MRS_ACT_NONE && nanflag[el] && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
+
+    if (doit) {
+        V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
+        if (ACT != MRS_ACT_NONE) {
+            const MrsParams &P = A.P;
+            Observed ob;
+            observe<true, true>(p, q, v, w, ob);
+            double rpm[4];
+            constexpr bool NEEDS_PID = (ACT >= MRS_ACT_TARGET_ACCEL);
+            if (NEEDS_PID) {
+                Pid s;
+                const double *g = A.b.pid64 + a;
+                const float *h = A.b.pid32 + a;
+                s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T];
+                s.dvx = g[3 * T]; s.dvy = g[4 * T]; s.dvz = g[5 * T];
+                s.ivx = g[6 * T]; s.ivy = g[7 * T]; s.ivz = g[8 * T];
+                s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
+                s.lvx = h[0]; s.lvy = h[T]; s.lvz = h[2 * T];
+                s.ltx = h[3 * T]; s.lty = h[4 * T]; s.ltz = h[5 * T];
+                const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
+                if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
+                    const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
+                    attitude_control(P, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
+                } else {
+                    V3 ta;
+                    if (ACT == MRS_ACT_TARGET_VEL) ta = vel_control_accel(P, s, ob, act[0], act[1], act[2]);
+                    else if (ACT == MRS_ACT_TARGET_POS) ta = pos_control_accel(P, s, ob, act[0], act[1], act[2]);
+                    else ta = v3((double)act[0], (double)act[1], (double)act[2]);
+                    accel_control(P, s, ta, R, ob, rpm);
+                }
+                double *go = A.b.pid64 + a;
+                float *ho = A.b.pid32 + a;
+                if (ACT == MRS_ACT_TARGET_POS) { go[0] = s.ipx; go[T] = s.ipy; go[2 * T] = s.ipz; }
+                if (ACT == MRS_ACT_TARGET_VEL) {
+                    go[3 * T] = s.dvx; go[4 * T] = s.dvy; go[5 * T] = s.dvz;
+                    go[6 * T] = s.ivx; go[7 * T] = s.ivy; go[8 * T] = s.ivz;
+                    ho[0] = s.lvx; ho[T] = s.lvy; ho[2 * T] = s.lvz;
+                    ho[3 * T] = s.ltx; ho[4 * T] = s.lty; ho[5 * T] = s.ltz;
+                }
+                go[9 * T] = s.iox; go[10 * T] = s.ioy; go[11 * T] = s.ioz;
+            } else if (ACT == MRS_ACT_SET_CONTROL) {
+                set_control(P, act[0], act[1], act[2], act[3], rpm);
+            } else {
+                rpm[0] = act[0]; rpm[1] = act[1]; rpm[2] = act[2]; rpm[3] = act[3];
+            }
+            if (A.b.rpm) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) A.b.rpm[k * T + a] = (float)rpm[k];
+            }
+            // ---- Quadcopter.set_speeds (Quadcopter.py:38-45): rotor thrusts + yaw reaction torque.
+            // With ACTION_TYPE=set_speeds the reference's arithmetic is float32 (float32 action tensor).
+            double F[4], sumw, zt;
+            float s32[4] = {act[0], act[1], act[2], act[3]};
+            if (ACT == MRS_ACT_SET_SPEEDS) {
+                float t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sq = __fmul_rn(s32[k], s32[k]);
+                    F[k] = (double)__fmul_rn(sq, (float)P.kf);
+                    t[k] = __fmul_rn(sq, (float)P.km);
+                }
+                zt = (double)__fadd_rn(__fsub_rn(__fadd_rn(-t[0], t[1]), t[2]), t[3]);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fdiv_rn(__fmul_rn((float)(2 * kPi), s32[k]), 60.f));
+                sumw = (double)acc;
+            } else {
+                double t[4];
+                sumw = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double sq = rpm[k] * rpm[k];
+                    F[k] = sq * P.kf; t[k] = sq * P.km;
+                    sumw += 2 * kPi * rpm[k] / 60;
+                }
+                zt = ((-t[0] + t[1]) - t[2]) + t[3];
+            }
+            // ---- Quadcopter.dynamics ground effect (Quadcopter.py:70-87)
+            const M3 Rb = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+            const bool gnd_on = (ob.roll < (float)(kPi / 2)) && (ob.pitch < (float)(kPi / 2)); // :80 np.abs(bool)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double h = p[2] + (Rb.m20 * P.prop_x[k] + Rb.m21 * P.prop_y[k] + Rb.m22 * P.prop_z[k]);
+                h = h < A.hclip ? A.hclip : h; // :77
+                const double ratio = P.prop_radius / (4 * h);
+                double g;
+                if (ACT == MRS_ACT_SET_SPEEDS) {
+                    const float sq = __fmul_rn(s32[k], s32[k]);
+                    g = (double)__fmul_rn(__fmul_rn(sq, (float)P.kf), (float)P.gnd_eff_coeff) * (ratio * ratio);
+                } else {
+                    g = ((rpm[k] * rpm[k]) * P.kf) * P.gnd_eff_coeff * (ratio * ratio);
+                }
+                const double f = F[k] + (gnd_on ? g : 0.0);
+                fb.z += f;
+                tb.x += P.prop_y[k] * f;   // r x (0,0,f) at the prop link COM (cf2x.urdf:42-78)
+                tb.y += -P.prop_x[k] * f;
+            }
+            tb.z += zt;
+            // ---- drag (Quadcopter.py:88-98): R32 (c .* v32), applied in LINK_FRAME => used as a body-frame force
+            {
+                const double t0 = (-1 * P.drag_xy * sumw) * (double)ob.vx, t1 = (-1 * P.drag_xy * sumw) * (double)ob.vy,
+                             t2 = (-1 * P.drag_z * sumw) * (double)ob.vz;
+                fb.x += (double)ob.r00 * t0 + (double)ob.r01 * t1 + (double)ob.r02 * t2;
+                fb.y += (double)ob.r10 * t0 + (double)ob.r11 * t1 + (double)ob.r12 * t2;
+                fb.z += (double)ob.r20 * t0 + (double)ob.r21 * t1 + (double)ob.r22 * t2;
+            }
+            // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane
+            {
+                const float4 *tile_env = lds_tile + el * A.N;
+                const float pr32 = (float)P.prop_radius, dw1 = (float)P.dw1, dw2 = (float)P.dw2, dw3 = (float)P.dw3;
+                double acc = 0;
+                for (int j = 0; j < A.N; ++j) {
+                    const float4 pj = tile_env[j];
+                    const float f = downwash_pair(__fsub_rn(pj.x, ob.px), __fsub_rn(pj.y, ob.py), __fsub_rn(pj.z, ob.pz), pr32, dw1, dw2, dw3);
+                    acc += (double)f;
+                }
+                fb.z += acc;
+            }
+        }
+        integrate(A.P, p, q, v, w, fb, tb);
+        store_state(A.b, a, T, p, q, v, w);
+    }
+    if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
+    if (A.do_adj) {
+        __syncthreads(); // every lane is done reading the pre-step tile
+        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+        __syncthreads();
+        if (live) adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+    }
+}
+
+// standalone observe / adjacency (reset()/set() -> calc_Xk, DataGenerator's calc_Ak after reset)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
+{
+    extern __shared__ float4 lds_tile[];
+    const int tid = threadIdx.x;
+    const int el = tid / A.N;
+    const int i = tid - el * A.N;
+    const int e = blockIdx.x * A.epb + el;
+    const bool live = (el < A.epb) && (e < A.E);
+    const size_t a = live ? (size_t)e * A.N + i : 0;
+    double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+    if (live) load_state(A.b, a, (size_t)A.T, p, q, v, w);
+    if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
+    if (A.do_adj) {
+        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+        __syncthreads();
+        if (live) adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+    }
+}
+
+// packed (M,N,W) -> dense float32 (M,N,N), one thread per output element (coalesced along j)
+__global__ void k_adj_expand(const uint64_t *__restrict__ packed, float *__restrict__ dense, int N, int W, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t row = idx / N;
+    const int j = (int)(idx - row * N);
+    const uint64_t bits = packed[row * W + (j >> 6)];
+    dense[idx] = (float)((bits >> (j & 63)) & 1ull);
+}
+
+// Environment.set_state / Object.set_state (Environment.py:97-103, Object.py:42-65)
+struct SetArgs {
+    MrsBuffers b;
+    const float *pos, *ori, *vel, *angvel;
+    const double *pos64, *quat64, *vel64, *angvel64;
+    const uint8_t *mask;
+    int ori_kind, N;
+    size_t T;
+};
+__global__ void k_set_state(const SetArgs S)
+{
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= S.T) return;
+    const size_t T = S.T;
+    if (S.mask && !S.mask[a / S.N]) return;
+    if (S.pos) for (int k = 0; k < 3; ++k) S.b.pos[k * T + a] = (double)S.pos[a * 3 + k];
+    if (S.vel) for (int k = 0; k < 3; ++k) S.b.vel[k * T + a] = (double)S.vel[a * 3 + k];
+    if (S.angvel) for (int k = 0; k < 3; ++k) S.b.angvel[k * T + a] = (double)S.angvel[a * 3 + k];
+    if (S.pos64) for (int k = 0; k < 3; ++k) S.b.pos[k * T + a] = S.pos64[a * 3 + k];
+    if (S.vel64) for (int k = 0; k < 3; ++k) S.b.vel[k * T + a] = S.vel64[a * 3 + k];
+    if (S.angvel64) for (int k = 0; k < 3; ++k) S.b.angvel[k * T + a] = S.angvel64[a * 3 + k];
+    if (S.quat64) for (int k = 0; k < 4; ++k) S.b.quat[k * T + a] = S.quat64[a * 4 + k];
+    if (S.ori) {
+        double q[4];
+        if (S.ori_kind == MRS_ORI_EULER) { // Object.py:54-56
+            euler_to_quat((double)S.ori[a * 3], (double)S.ori[a * 3 + 1], (double)S.ori[a * 3 + 2], q);
+        } else if (S.ori_kind == MRS_ORI_QUAT) { // passthrough
+            for (int k = 0; k < 4; ++k) q[k] = (double)S.ori[a * 4 + k];
+        } else { // Object.py:51-53 R.from_matrix(ori).as_quat(): Shepperd's method on the given matrix
+            const float *m = S.ori + a * 9;
+            const double m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+            const double tr = m00 + m11 + m22;
+            if (tr >= m00 && tr >= m11 && tr >= m22) {
+                q[3] = 1 + tr; q[0] = m21 - m12; q[1] = m02 - m20; q[2] = m10 - m01;
+            } else if (m00 >= m11 && m00 >= m22) {
+                q[0] = 1 - tr + 2 * m00; q[1] = m10 + m01; q[2] = m20 + m02; q[3] = m21 - m12;
+            } else if (m11 >= m22) {
+                q[1] = 1 - tr + 2 * m11; q[0] = m10 + m01; q[2] = m21 + m12; q[3] = m02 - m20;
+            } else {
+                q[2] = 1 - tr + 2 * m22; q[0] = m20 + m02; q[1] = m21 + m12; q[3] = m10 - m01;
+            }
+            const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (int k = 0; k < 4; ++k) q[k] /= n;
+        }
+        for (int k = 0; k < 4; ++k) S.b.quat[k * T + a] = q[k];
+    }
+}
+
+__global__ void k_pid_reset(MrsBuffers b, const uint8_t *mask, int N, size_t T)
+{
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= T) return;
+    if (mask && !mask[a / N]) return;
+    for (int k = 0; k < 12; ++k) b.pid64[k * T + a] = 0.0;
+    for (int k = 0; k < 6; ++k) b.pid32[k * T + a] = __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------ spawn
+// Counter-based RNG: splitmix64 over (seed, global env, agent, draw#) -> independent of sharding.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t env, uint32_t agent, uint32_t draw)
+{
+    const uint64_t h = splitmix64(splitmix64(seed ^ (env * 0xD1342543DE82EF95ull)) ^ ((uint64_t)agent << 32 | draw));
+    return ((h >> 40) + 0.5f) * (1.0f / 16777216.0f); // (0,1)
+}
+
+struct SpawnArgs {
+    MrsBuffers b;
+    uint64_t seed;
+    int64_t env_base;
+    const uint8_t *mask;
+    int E, N, max_rounds;
+    float min_dist;
+    float ori_lo[3], ori_hi[3];
+    size_t T;
+};
+
+// MRS.generate_start_pos (MRS.py:127-154) for the default spawn distribution (MRS.py:69-78):
+// one workgroup per env; positions and the collision graph live in LDS.
+__global__ void k_spawn(const SpawnArgs S)
+{
+    extern __shared__ float4 sp[]; // N positions, then N ints (collision count), then N ints (resample flag)
+    int *cnt = reinterpret_cast<int *>(sp + S.N);
+    int *flag = cnt + S.N;
+    __shared__ int s_total;
+    const int e = blockIdx.x;
+    if (S.mask && !S.mask[e]) return;
+    const uint64_t ge = (uint64_t)(S.env_base + e);
+    const int tid = threadIdx.x;
+    const bool live = tid < S.N;
+    uint32_t draws = 0;
+    auto sample = [&](int i) {
+        // xy ~ Normal(0,1) pushed through SphereTransform(radius=1, within=True) (Util.py:176-195):
+        // points outside the unit disc are pulled onto its rim; z ~ U[1,3]
+        const float u1 = u01(S.seed, ge, i, draws), u2 = u01(S.seed, ge, i, draws + 1), u3 = u01(S.seed, ge, i, draws + 2);
+        const float r = sqrtf(-2.f * logf(u1));
+        float x = r * cosf(6.2831853f * u2), y = r * sinf(6.2831853f * u2);
+        const float mag = sqrtf(x * x + y * y);
+        if (mag > 1.f) { x /= mag; y /= mag; }
+        sp[i] = make_float4(x, y, 1.f + 2.f * u3, 0.f);
+    };
+    if (live) { sample(tid); flag[tid] = 0; }
+    draws += 3;
+    __syncthreads();
+    int round = 0;
+    for (;; ++round) {
+        if (live) { // codist < 2*AGENT_RADIUS (MRS.py:135-138)
+            int c = 0;
+            const float4 me = sp[tid];
+            for (int j = 0; j < S.N; ++j) {
+                const float4 pj = sp[j];
+                const float dx = me.x - pj.x, dy = me.y - pj.y, dz = me.z - pj.z;
+                c += (j != tid) && (sqrtf(dx * dx + dy * dy + dz * dz) < S.min_dist);
+            }
+            cnt[tid] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int j = 0; j < S.N; ++j) tot += cnt[j];
+            s_total = tot;
+            // greedy (MRS.py:140-144): repeatedly take the most-colliding agent, drop its row/column
+            while (tot > 0 && round < S.max_rounds) {
+                int best = 0;
+                for (int j = 1; j < S.N; ++j) if (cnt[j] > cnt[best]) best = j;
+                if (cnt[best] == 0) break;
+                flag[best] = 1;
+                const float4 pb = sp[best];
+                for (int j = 0; j < S.N; ++j) {
+                    if (j == best || flag[j]) continue;
+                    const float4 pj = sp[j];
+                    const float dx = pb.x - pj.x, dy = pb.y - pj.y, dz = pb.z - pj.z;
+                    if (sqrtf(dx * dx + dy * dy + dz * dz) < S.min_dist) { cnt[j]--; tot -= 2; }
+                }
+                cnt[best] = 0;
+            }
+        }
+        __syncthreads();
+        if (s_total == 0 || round >= S.max_rounds) break;
+        if (live && flag[tid]) { sample(tid); flag[tid] = 0; } // MRS.py:146-151
+        draws += 3;
+        __syncthreads();
+    }
+    if (tid == 0 && s_total != 0 && S.b.status) atomicOr(&S.b.status[e], MRS_STATUS_SPAWN_FAIL);
+    if (live) {
+        const size_t a = (size_t)e * S.N + tid, T = S.T;
+        const float4 me = sp[tid];
+        S.b.pos[a] = (double)me.x; S.b.pos[T + a] = (double)me.y; S.b.pos[2 * T + a] = (double)me.z;
+        // MRS.generate_start_ori (MRS.py:157-161): randrange(lo, hi) per axis
+        float eul[3];
+        for (int k = 0; k < 3; ++k) {
+            const float u = u01(S.seed ^ 0xA5A5A5A5ull, ge, tid, 0x40000000u + k);
+            eul[k] = S.ori_lo[k] + u * (S.ori_hi[k] - S.ori_lo[k]);
+        }
+        double q[4];
+        euler_to_quat((double)eul[0], (double)eul[1], (double)eul[2], q);
+        for (int k = 0; k < 4; ++k) S.b.quat[k * T + a] = q[k];
+        for (int k = 0; k < 3; ++k) { S.b.vel[k * T + a] = 0.0; S.b.angvel[k * T + a] = 0.0; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- host
+struct MrsHandle {
+    MrsParams P;
+    int E, N, device;
+    int block, epb, W;
+    double hclip;
+};
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static int hipfail(hipError_t e, const char *where)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+
+extern "C" int mrs_abi_version(void) { return MRS_ABI_VERSION; }
+extern "C" const char *mrs_last_error(void) { return g_err; }
+
+extern "C" int mrs_params_default(MrsParams *p)
+{
+    if (!p) return fail(MRS_E_ARG, "mrs_params_default: NULL");
+    memset(p, 0, sizeof(*p));
+    // cf2x.urdf:5,11,12,34,42-78 (Quadcopter.read_attributes, Quadcopter.py:119-150)
+    p->arm = 0.0397; p->kf = 3.16e-10; p->km = 7.94e-12; p->thrust2weight = 2.25;
+    p->gnd_eff_coeff = 11.36859; p->prop_radius = 2.31348e-2; p->drag_xy = 9.1785e-7; p->drag_z = 10.311e-7;
+    p->dw1 = 2267.18; p->dw2 = .16; p->dw3 = -.11;
+    p->mass = 0.027; p->ixx_file = 1.4e-5; p->iyy_file = 1.4e-5; p->izz_file = 2.17e-5;
+    const double px[4] = {0.028, -0.028, -0.028, 0.028}, py[4] = {0.028, 0.028, -0.028, -0.028};
+    for (int k = 0; k < 4; ++k) { p->prop_x[k] = px[k]; p->prop_y[k] = py[k]; p->prop_z[k] = 0.0; }
+    p->coll_radius = 0.06; p->coll_half_len = 0.0125;
+    p->gravity = 9.81; p->dt = 0.01; p->ctrl_gravity = 9.81; p->ctrl_dt = 0.01; // BulletSim.py:13-14, :52-57
+    // [BULLET-KNOWLEDGE] inertia of the collision hull's AABB (+2 x 0.001 margin), damping 0.04f, clamp 100
+    const double lx = 2 * (p->coll_radius + 0.002), lz = 2 * (p->coll_half_len + 0.002);
+    p->inertia[0] = p->inertia[1] = p->mass / 12.0 * (lx * lx + lz * lz);
+    p->inertia[2] = p->mass / 12.0 * (lx * lx + lx * lx);
+    p->lin_damp = (double)0.04f; p->ang_damp = (double)0.04f; p->max_coord_vel = 100.0; p->use_gyro = 1;
+    p->ground_z = 0.5; p->friction = 1.5 * 0.5; p->erp = 0.2; p->contact_threshold = 0.02; // plane.urdf:5,24
+    p->solver_iters = 10; p->enable_contact = 1;
+    return 0;
+}
+
+extern "C" int mrs_params_derived(const MrsParams *p, double out[7])
+{
+    if (!p || !out) return fail(MRS_E_ARG, "mrs_params_derived: NULL");
+    const double gf = p->gravity * p->mass; // Quadcopter.py:156-162
+    const double hover = sqrt(gf / (4 * p->kf));
+    const double maxrpm = sqrt((p->thrust2weight * gf) / (4 * p->kf));
+    const double maxthrust = 4. * p->kf * maxrpm * maxrpm;
+    out[0] = gf; out[1] = hover; out[2] = maxrpm; out[3] = maxthrust;
+    out[4] = sqrt(2.0) * p->arm * p->kf * maxrpm * maxrpm;
+    out[5] = 2. * p->km * maxrpm * maxrpm;
+    out[6] = 0.25 * p->prop_radius * sqrt((15 * maxrpm * maxrpm * p->kf * p->gnd_eff_coeff) / maxthrust);
+    return 0;
+}
+
+extern "C" int mrs_adj_words(int n_agents) { return n_agents > 0 ? (n_agents + 63) / 64 : MRS_E_ARG; }
+
+static int obs_width(int f)
+{
+    switch (f) {
+    case MRS_OBS_POS: case MRS_OBS_VEL: case MRS_OBS_EULER: case MRS_OBS_ANGVEL: return 3;
+    case MRS_OBS_QUAT: return 4;
+    default: return -1;
+    }
+}
+extern "C" int mrs_obs_dim(const int32_t *fields, int n)
+{
+    if (n < 0 || n > MRS_OBS_MAX_FIELDS || (n > 0 && !fields)) return MRS_E_ARG;
+    int d = 0;
+    for (int i = 0; i < n; ++i) {
+        const int w = obs_width(fields[i]);
+        if (w < 0) return MRS_E_ARG;
+        d += w;
+    }
+    return d;
+}
+
+extern "C" int mrs_set_params(MrsHandle *h, const MrsParams *params)
+{
+    if (!h || !params) return fail(MRS_E_ARG, "mrs_set_params: NULL");
+    h->P = *params;
+    double d[7];
+    mrs_params_derived(params, d);
+    h->hclip = d[6];
+    return 0;
+}
+
+extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int device, MrsHandle **out)
+{
+    if (!params || !out) return fail(MRS_E_ARG, "mrs_create: NULL argument");
+    if (n_envs < 1 || n_agents < 1) return fail(MRS_E_ARG, "mrs_create: n_envs and n_agents must be >= 1");
+    if (n_agents > 1024) return fail(MRS_E_ARG, "mrs_create: N_AGENTS > 1024 not supported (one env per workgroup)");
+    if ((size_t)n_envs * (size_t)n_agents > 0x7fffffffull) return fail(MRS_E_ARG, "mrs_create: E*N overflows int32");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(MRS_E_NO_DEVICE, "mrs_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MRS_E_ARG, "mrs_create: bad device index");
+    MrsHandle *h = new (std::nothrow) MrsHandle();
+    if (!h) return fail(MRS_E_ARG, "mrs_create: out of host memory");
+    h->E = n_envs; h->N = n_agents; h->device = device;
+    if (n_agents <= 256) { h->block = 256; h->epb = 256 / n_agents; }
+    else { h->block = 1024; h->epb = 1; }
+    h->W = (n_agents + 63) / 64;
+    mrs_set_params(h, params);
+    *out = h;
+    return 0;
+}
+
+extern "C" void mrs_destroy(MrsHandle *h) { delete h; }
+
+static float d2_threshold(double comm_range)
+{
+    // largest float t with sqrtf(t) <= (float)comm_range, so that "sqrt(d2) <= R" == "d2 <= t" exactly
+    const float r = (float)comm_range;
+    if (!(r >= 0.f)) return -1.f;
+    float t = r * r;
+    while (sqrtf(nextafterf(t, INFINITY)) <= r) t = nextafterf(t, INFINITY);
+    while (t > 0.f && sqrtf(t) > r) t = nextafterf(t, -INFINITY);
+    return t;
+}
+
+static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs, double comm_range, StepArgs &A)
+{
+    memset(&A, 0, sizeof(A));
+    A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
+    const int D = mrs_obs_dim(obs_fields, n_obs);
+    if (D < 0) return fail(MRS_E_ARG, "bad observation field list");
+    A.n_obs = n_obs; A.D = D;
+    for (int i = 0; i < n_obs; ++i) A.obs_fields[i] = obs_fields[i];
+    if (n_obs > 0 && !b->obs) A.n_obs = 0;
+    A.do_adj = (b->adj != nullptr) && !std::isnan(comm_range);
+    A.comm_inf = std::isinf(comm_range) && comm_range > 0;
+    A.d2_thresh = A.comm_inf ? INFINITY : d2_threshold(comm_range);
+    return 0;
+}
+
+template <int ACT>
+static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st)
+{
+    const int grid = (h->E + h->epb - 1) / h->epb;
+    const size_t lds = (size_t)h->block * sizeof(float4) + 256 * sizeof(int);
+    if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256>), dim3(grid), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_step<ACT, 1024>), dim3(grid), dim3(1024), lds, st, A);
+    return hipGetLastError();
+}
+
+extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
+                        const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream)
+{
+    if (!h || !b) return fail(MRS_E_ARG, "mrs_step: NULL handle/buffers");
+    if (!b->pos || !b->quat || !b->vel || !b->angvel) return fail(MRS_E_ARG, "mrs_step: state buffers missing");
+    if (action_type < MRS_ACT_NONE || action_type > MRS_ACT_TARGET_ORI)
+        return fail(MRS_E_ACTION_TYPE, "mrs_step: unknown ACTION_TYPE (the reference raises AttributeError, Environment.py:92)");
+    if (action_type != MRS_ACT_NONE && !actions) return fail(MRS_E_ARG, "mrs_step: actions is NULL");
+    if (action_type >= MRS_ACT_TARGET_ACCEL && (!b->pid64 || !b->pid32)) return fail(MRS_E_ARG, "mrs_step: PID buffers missing");
+    StepArgs A;
+    int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
+    if (rc) return rc;
+    A.actions = actions;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    switch (action_type) {
+    case MRS_ACT_NONE: e = launch_step<MRS_ACT_NONE>(h, A, st); break;
+    case MRS_ACT_SET_SPEEDS: e = launch_step<MRS_ACT_SET_SPEEDS>(h, A, st); break;
+    case MRS_ACT_SET_CONTROL: e = launch_step<MRS_ACT_SET_CONTROL>(h, A, st); break;
+    case MRS_ACT_TARGET_ACCEL: e = launch_step<MRS_ACT_TARGET_ACCEL>(h, A, st); break;
+    case MRS_ACT_TARGET_VEL: e = launch_step<MRS_ACT_TARGET_VEL>(h, A, st); break;
+    case MRS_ACT_TARGET_POS: e = launch_step<MRS_ACT_TARGET_POS>(h, A, st); break;
+    default: e = launch_step<MRS_ACT_TARGET_ORI>(h, A, st); break;
+    }
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_step launch");
+}
+
+static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)
+{
+    const int grid = (h->E + h->epb - 1) / h->epb;
+    const size_t lds = (size_t)h->block * sizeof(float4);
+    if (h->block == 256) hipLaunchKernelGGL((k_observe_adj<256>), dim3(grid), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_observe_adj<1024>), dim3(grid), dim3(1024), lds, st, A);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "observe/adjacency launch");
+}
+
+extern "C" int mrs_observe(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs_fields, void *stream)
+{
+    if (!h || !b || !b->obs) return fail(MRS_E_ARG, "mrs_observe: NULL handle/buffers/obs");
+    StepArgs A;
+    int rc = fill_common(h, b, obs_fields, n_obs_fields, NAN, A);
+    if (rc) return rc;
+    return launch_observe_adj(h, A, (hipStream_t)stream);
+}
+
+extern "C" int mrs_adjacency(MrsHandle *h, const MrsBuffers *b, double comm_range, void *stream)
+{
+    if (!h || !b || !b->adj) return fail(MRS_E_ARG, "mrs_adjacency: NULL handle/buffers/adj");
+    if (std::isnan(comm_range)) return fail(MRS_E_ARG, "mrs_adjacency: comm_range is NaN");
+    StepArgs A;
+    int rc = fill_common(h, b, nullptr, 0, comm_range, A);
+    if (rc) return rc;
+    return launch_observe_adj(h, A, (hipStream_t)stream);
+}
+
+extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int n_matrices, void *stream)
+{
+    if (!h || !packed || !dense || n_matrices < 0) return fail(MRS_E_ARG, "mrs_adjacency_expand: bad argument");
+    const size_t total = (size_t)n_matrices * h->N * h->N;
+    if (total == 0) return 0;
+    const int block = 256;
+    const size_t grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffull) return fail(MRS_E_ARG, "mrs_adjacency_expand: too large");
+    hipLaunchKernelGGL(k_adj_expand, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, packed, dense, h->N, h->W, total);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_adjacency_expand launch");
+}
+
+static int launch_set(MrsHandle *h, const SetArgs &S, hipStream_t st)
+{
+    const int block = 256;
+    const unsigned grid = (unsigned)((S.T + block - 1) / block);
+    hipLaunchKernelGGL(k_set_state, dim3(grid), dim3(block), 0, st, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_set_state launch");
+}
+
+extern "C" int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos, const float *ori, int ori_kind,
+                             const float *vel, const float *angvel, const uint8_t *env_mask, void *stream)
+{
+    if (!h || !b) return fail(MRS_E_ARG, "mrs_set_state: NULL handle/buffers");
+    if (ori && (ori_kind < MRS_ORI_EULER || ori_kind > MRS_ORI_MATRIX)) return fail(MRS_E_ARG, "mrs_set_state: bad ori_kind");
+    SetArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.pos = pos; S.ori = ori; S.vel = vel; S.angvel = angvel; S.mask = env_mask; S.ori_kind = ori_kind;
+    S.N = h->N; S.T = (size_t)h->E * h->N;
+    return launch_set(h, S, (hipStream_t)stream);
+}
+
+extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, const double *quat,
+                                 const double *vel, const double *angvel, const uint8_t *env_mask, void *stream)
+{
+    if (!h || !b) return fail(MRS_E_ARG, "mrs_set_state_f64: NULL handle/buffers");
+    SetArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.pos64 = pos; S.quat64 = quat; S.vel64 = vel; S.angvel64 = angvel; S.mask = env_mask;
+    S.N = h->N; S.T = (size_t)h->E * h->N;
+    return launch_set(h, S, (hipStream_t)stream);
+}
+
+extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream)
+{
+    if (!h || !b || !b->pid64 || !b->pid32) return fail(MRS_E_ARG, "mrs_pid_reset: NULL handle/buffers");
+    const size_t T = (size_t)h->E * h->N;
+    const int block = 256;
+    hipLaunchKernelGGL(k_pid_reset, dim3((unsigned)((T + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, *b, env_mask, h->N, T);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_pid_reset launch");
+}
+
+extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_index_base, double agent_radius,
+                         const float ori_lo[3], const float ori_hi[3], int max_rounds, const uint8_t *env_mask, void *stream)
+{
+    if (!h || !b || !ori_lo || !ori_hi) return fail(MRS_E_ARG, "mrs_spawn: NULL argument");
+    if (max_rounds < 1) return fail(MRS_E_ARG, "mrs_spawn: max_rounds must be >= 1");
+    SpawnArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.seed = seed; S.env_base = env_index_base; S.mask = env_mask; S.E = h->E; S.N = h->N;
+    S.max_rounds = max_rounds; S.min_dist = (float)(2 * agent_radius); S.T = (size_t)h->E * h->N;
+    for (int k = 0; k < 3; ++k) { S.ori_lo[k] = ori_lo[k]; S.ori_hi[k] = ori_hi[k]; }
+    const int block = ((h->N + 63) / 64) * 64;
+    const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
+    hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn launch");
+}

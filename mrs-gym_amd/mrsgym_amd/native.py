@@ -1,0 +1,287 @@
+"""ctypes binding of the C-ABI in include/mrs_hip.h (libmrs_hip.so).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present the product path
+raises.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libmrs_hip.so")
+
+ACT = {
+    None: 0,
+    "set_speeds": 1,
+    "set_control": 2,
+    "set_target_accel": 3,
+    "set_target_vel": 4,
+    "set_target_pos": 5,
+    "set_target_ori": 6,
+}
+ACT_DIM = {0: 0, 1: 4, 2: 4, 3: 3, 4: 3, 5: 3, 6: 3}
+OBS = {"pos": 0, "vel": 1, "ori": 2, "euler": 2, "angvel": 3, "quat": 4}
+OBS_WIDTH = {0: 3, 1: 3, 2: 3, 3: 3, 4: 4}
+ORI_EULER, ORI_QUAT, ORI_MATRIX = 0, 1, 2
+STATUS_NAN_ACTION, STATUS_SPAWN_FAIL = 1, 2
+EXPORTS = [
+    "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
+    "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
+    "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn",
+]
+
+
+class MrsParams(C.Structure):
+    _fields_ = [
+        ("mass", C.c_double), ("arm", C.c_double), ("kf", C.c_double), ("km", C.c_double), ("thrust2weight", C.c_double),
+        ("ixx_file", C.c_double), ("iyy_file", C.c_double), ("izz_file", C.c_double),
+        ("gnd_eff_coeff", C.c_double), ("prop_radius", C.c_double), ("drag_xy", C.c_double), ("drag_z", C.c_double),
+        ("dw1", C.c_double), ("dw2", C.c_double), ("dw3", C.c_double),
+        ("prop_x", C.c_double * 4), ("prop_y", C.c_double * 4), ("prop_z", C.c_double * 4),
+        ("coll_radius", C.c_double), ("coll_half_len", C.c_double),
+        ("gravity", C.c_double), ("dt", C.c_double), ("ctrl_gravity", C.c_double), ("ctrl_dt", C.c_double),
+        ("inertia", C.c_double * 3),
+        ("lin_damp", C.c_double), ("ang_damp", C.c_double), ("max_coord_vel", C.c_double),
+        ("use_gyro", C.c_int32), ("enable_contact", C.c_int32),
+        ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("contact_threshold", C.c_double),
+        ("solver_iters", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class MrsBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("pos", "quat", "vel", "angvel", "pid64", "pid32", "obs", "adj", "rpm", "status")]
+
+
+_lib = None
+
+
+class MrsNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmrs_hip.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MrsNativeError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+        L.mrs_abi_version.restype = C.c_int
+        L.mrs_last_error.restype = C.c_char_p
+        L.mrs_params_default.argtypes = [C.POINTER(MrsParams)]
+        L.mrs_params_derived.argtypes = [C.POINTER(MrsParams), C.POINTER(C.c_double)]
+        L.mrs_create.argtypes = [C.POINTER(MrsParams), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.mrs_destroy.argtypes = [vp]
+        L.mrs_destroy.restype = None
+        L.mrs_set_params.argtypes = [vp, C.POINTER(MrsParams)]
+        L.mrs_adj_words.argtypes = [C.c_int]
+        L.mrs_obs_dim.argtypes = [i32p, C.c_int]
+        L.mrs_pid_reset.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp]
+        L.mrs_set_state.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mrs_set_state_f64.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, vp, vp, vp, vp]
+        L.mrs_step.argtypes = [vp, C.POINTER(MrsBuffers), vp, C.c_int, i32p, C.c_int, C.c_double, vp]
+        L.mrs_observe.argtypes = [vp, C.POINTER(MrsBuffers), i32p, C.c_int, vp]
+        L.mrs_adjacency.argtypes = [vp, C.POINTER(MrsBuffers), C.c_double, vp]
+        L.mrs_adjacency_expand.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.mrs_spawn.argtypes = [vp, C.POINTER(MrsBuffers), C.c_uint64, C.c_int64, C.c_double,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, vp, vp]
+        for n in EXPORTS:
+            if n not in ("mrs_last_error", "mrs_destroy"):
+                getattr(L, n).restype = C.c_int
+        if L.mrs_abi_version() != 1:
+            raise MrsNativeError("libmrs_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MrsNativeError("%s failed (%d): %s" % (what, rc, lib().mrs_last_error().decode()))
+
+
+def default_params():
+    p = MrsParams()
+    _check(lib().mrs_params_default(C.byref(p)), "mrs_params_default")
+    return p
+
+
+def derived(p):
+    out = (C.c_double * 7)()
+    _check(lib().mrs_params_derived(C.byref(p), out), "mrs_params_derived")
+    names = ["GravityForce", "HoverRPM", "MaxRPM", "MaxThrust", "MaxXYTorque", "MaxZTorque", "GroundEffectHClip"]
+    return dict(zip(names, list(out)))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class SwarmShard:
+    """Device-resident state of E envs x N quadcopters on one GPU + the kernels that advance it.
+
+    Thin object over the C-ABI: owns the torch tensors (SoA, agent-major) and a MrsHandle.
+    """
+
+    def __init__(self, n_envs, n_agents, device, params=None, obs_fields=("pos", "vel"), want_rpm=False):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise MrsNativeError("mrsgym_amd runs on an AMD GPU only (device=%s); there is no CPU path" % device)
+        if not torch.cuda.is_available():
+            raise MrsNativeError("no GPU visible to PyTorch-ROCm")
+        self.L = lib()
+        self.E, self.N = int(n_envs), int(n_agents)
+        self.T = self.E * self.N
+        self.device = device
+        self.params = params or default_params()
+        self.W = self.L.mrs_adj_words(self.N)
+        h = C.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        _check(self.L.mrs_create(C.byref(self.params), self.E, self.N, idx, C.byref(h)), "mrs_create")
+        self.h = h
+        f64 = dict(dtype=torch.float64, device=device)
+        self.pos = torch.zeros(3, self.T, **f64)
+        self.quat = torch.zeros(4, self.T, **f64)
+        self.quat[3] = 1.0
+        self.vel = torch.zeros(3, self.T, **f64)
+        self.angvel = torch.zeros(3, self.T, **f64)
+        self.pid64 = torch.zeros(12, self.T, **f64)
+        self.pid32 = torch.full((6, self.T), float("nan"), dtype=torch.float32, device=device)
+        self.status = torch.zeros(self.E, dtype=torch.int32, device=device)
+        self.rpm = torch.zeros(4, self.T, dtype=torch.float32, device=device) if want_rpm else None
+        self.set_obs_fields(obs_fields)
+        self.adj = torch.zeros(self.E, self.N, self.W, dtype=torch.int64, device=device)
+        self.obs = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.mrs_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def set_obs_fields(self, fields):
+        codes = [OBS[f] if isinstance(f, str) else int(f) for f in fields]
+        self.obs_codes = (C.c_int32 * max(1, len(codes)))(*codes)
+        self.n_obs = len(codes)
+        self.D = sum(OBS_WIDTH[c] for c in codes)
+
+    def set_params(self, params):
+        self.params = params
+        _check(self.L.mrs_set_params(self.h, C.byref(params)), "mrs_set_params")
+
+    def _buffers(self, obs=None, adj=None):
+        b = MrsBuffers()
+        b.pos, b.quat, b.vel, b.angvel = self.pos.data_ptr(), self.quat.data_ptr(), self.vel.data_ptr(), self.angvel.data_ptr()
+        b.pid64, b.pid32 = self.pid64.data_ptr(), self.pid32.data_ptr()
+        b.obs = obs.data_ptr() if obs is not None else None
+        b.adj = adj.data_ptr() if adj is not None else None
+        b.rpm = self.rpm.data_ptr() if self.rpm is not None else None
+        b.status = self.status.data_ptr()
+        return b
+
+    @staticmethod
+    def _f32(x, device, shape):
+        if x is None:
+            return None
+        t = torch.as_tensor(x, device=device).to(torch.float32).reshape(shape).contiguous()
+        return t
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def set_state(self, pos=None, ori=None, vel=None, angvel=None, env_mask=None):
+        """Environment.set_state semantics: None keeps the current value (MRS.set)."""
+        E, N, dev = self.E, self.N, self.device
+        pos = self._f32(pos, dev, (E, N, 3))
+        vel = self._f32(vel, dev, (E, N, 3))
+        angvel = self._f32(angvel, dev, (E, N, 3))
+        kind = ORI_EULER
+        if ori is not None:
+            ori = torch.as_tensor(ori, device=dev).to(torch.float32)
+            tail = tuple(ori.shape[-2:])
+            if ori.shape[-1] == 3 and tail != (3, 3):
+                kind, ori = ORI_EULER, ori.reshape(E, N, 3).contiguous()
+            elif ori.shape[-1] == 4:
+                kind, ori = ORI_QUAT, ori.reshape(E, N, 4).contiguous()
+            else:
+                kind, ori = ORI_MATRIX, ori.reshape(E, N, 9).contiguous()
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=dev).to(torch.uint8).contiguous()
+        b = self._buffers()
+        _check(self.L.mrs_set_state(self.h, C.byref(b), _ptr(pos), _ptr(ori), kind, _ptr(vel), _ptr(angvel), _ptr(mask),
+                                    _stream(dev)), "mrs_set_state")
+
+    def set_state_f64(self, pos=None, quat=None, vel=None, angvel=None, env_mask=None):
+        dev = self.device
+
+        def g(x, k):
+            return None if x is None else torch.as_tensor(x, device=dev).to(torch.float64).reshape(self.E, self.N, k).contiguous()
+        pos, quat, vel, angvel = g(pos, 3), g(quat, 4), g(vel, 3), g(angvel, 3)
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=dev).to(torch.uint8).contiguous()
+        b = self._buffers()
+        _check(self.L.mrs_set_state_f64(self.h, C.byref(b), _ptr(pos), _ptr(quat), _ptr(vel), _ptr(angvel), _ptr(mask),
+                                        _stream(dev)), "mrs_set_state_f64")
+
+    def pid_reset(self, env_mask=None):
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
+        b = self._buffers()
+        _check(self.L.mrs_pid_reset(self.h, C.byref(b), _ptr(mask), _stream(self.device)), "mrs_pid_reset")
+
+    def step(self, actions, action_type, obs_out=None, adj_out=None, comm_range=float("nan")):
+        """One fused step.  actions: (E,N,adim) float32 device tensor (or None with action_type None)."""
+        at = action_type if isinstance(action_type, int) else ACT.get(action_type, -1)
+        if actions is None:
+            at = 0
+        elif at > 0:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            if actions.numel() != self.T * ACT_DIM[at]:
+                raise ValueError("actions has %d elements, expected (E,N,%d)" % (actions.numel(), ACT_DIM[at]))
+        b = self._buffers(obs_out, adj_out)
+        cr = float(comm_range) if adj_out is not None else float("nan")
+        rc = self.L.mrs_step(self.h, C.byref(b), _ptr(actions), at, self.obs_codes, self.n_obs if obs_out is not None else 0,
+                             cr, _stream(self.device))
+        if rc == -2:
+            raise AttributeError("'Quadcopter' object has no attribute %r" % (action_type,))   # Environment.py:92
+        _check(rc, "mrs_step")
+
+    def observe(self, obs_out):
+        b = self._buffers(obs_out, None)
+        _check(self.L.mrs_observe(self.h, C.byref(b), self.obs_codes, self.n_obs, _stream(self.device)), "mrs_observe")
+
+    def adjacency(self, adj_out, comm_range):
+        b = self._buffers(None, adj_out)
+        _check(self.L.mrs_adjacency(self.h, C.byref(b), float(comm_range), _stream(self.device)), "mrs_adjacency")
+
+    def adjacency_expand(self, packed, dense_out):
+        n = packed.numel() // (self.N * self.W)
+        _check(self.L.mrs_adjacency_expand(self.h, _ptr(packed), _ptr(dense_out), n, _stream(self.device)),
+               "mrs_adjacency_expand")
+
+    def spawn(self, seed, env_index_base=0, agent_radius=0.3, ori_lo=(0., 0., -math.pi / 2), ori_hi=(0., 0., math.pi / 2),
+              max_rounds=10000, env_mask=None):
+        lo = (C.c_float * 3)(*[float(x) for x in ori_lo])
+        hi = (C.c_float * 3)(*[float(x) for x in ori_hi])
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
+        b = self._buffers()
+        _check(self.L.mrs_spawn(self.h, C.byref(b), int(seed) & (2 ** 64 - 1), int(env_index_base), float(agent_radius),
+                                lo, hi, int(max_rounds), _ptr(mask), _stream(self.device)), "mrs_spawn")
+
+    # ------------------------------------------------------------------ views (E,N,k), zero-copy
+    def view(self, t):
+        k = t.shape[0]
+        return t.view(k, self.E, self.N).permute(1, 2, 0)
+
+    def state_dict(self):
+        return {k: getattr(self, k).clone() for k in ("pos", "quat", "vel", "angvel", "pid64", "pid32")}
+
+    def load_state_dict(self, sd):
+        for k in ("pos", "quat", "vel", "angvel", "pid64", "pid32"):
+            getattr(self, k).copy_(sd[k])

@@ -1,0 +1,307 @@
+"""GPU parity: the HIP path (through the C-ABI in libmrs_hip.so) against the CPU oracle on the same
+seeded inputs.  Tolerances: positions / orientations / velocities 1e-4 abs over 1000 steps
+(BASELINE.json north_star); adjacency bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from util_scenarios import ADIM, ActionStream, grid_spawn
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _mk(E, N, atype, obs_fields=("pos", "vel"), seed=0, params=None):
+    import mrsgym_amd
+    pos, eul = grid_spawn(E, N, seed=seed)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", obs_fields=obs_fields, want_rpm=True)
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z.astype(np.float64), angvel=z.astype(np.float64))
+    return sh, sw, pos
+
+
+def _gpu_state(sh):
+    return {k: sh.view(getattr(sh, k)).cpu().numpy() for k in ("pos", "quat", "vel", "angvel")}
+
+
+def _quat_err(a, b):
+    # q and -q are the same orientation
+    return np.minimum(np.abs(a - b).max(-1), np.abs(a + b).max(-1)).max()
+
+
+def _compare(sh, sw, tol, what):
+    g = _gpu_state(sh)
+    errs = dict(pos=np.abs(g["pos"] - sw.pos).max(), vel=np.abs(g["vel"] - sw.vel).max(),
+                angvel=np.abs(g["angvel"] - sw.angvel).max(), quat=_quat_err(g["quat"], sw.quat))
+    for k, v in errs.items():
+        assert v < tol, "%s: %s error %.3e >= %.1e (%s)" % (what, k, v, tol, errs)
+    return errs
+
+
+def test_set_state_and_observe_match_oracle():
+    import mrsgym_amd
+    E, N = 3, 7
+    rng = np.random.default_rng(5)
+    pos = rng.normal(0, 3, (E, N, 3)).astype(np.float32)
+    eul = (rng.uniform(-1, 1, (E, N, 3)) * [3.1, 1.5, 3.1]).astype(np.float32)
+    vel = rng.normal(0, 2, (E, N, 3)).astype(np.float32)
+    ang = rng.normal(0, 2, (E, N, 3)).astype(np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", obs_fields=("pos", "ori", "vel", "angvel", "quat"))
+    sh.set_state(pos=pos, ori=eul, vel=vel, angvel=ang)
+    sw = oracle.OracleSwarm(E, N)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=vel.astype(np.float64), angvel=ang.astype(np.float64))
+    g = _gpu_state(sh)
+    assert np.abs(g["quat"] - sw.quat).max() < 1e-15
+    assert np.array_equal(g["pos"], sw.pos) and np.array_equal(g["vel"], sw.vel)
+    obs = torch.zeros(E, N, sh.D, device="cuda:0")
+    sh.observe(obs)
+    o = sw.observe()
+    want = np.concatenate([o["pos"], o["euler"], o["vel"], o["angvel"], sw.quat.astype(np.float32)], -1)
+    np.testing.assert_allclose(obs.cpu().numpy(), want, rtol=0, atol=2e-7)
+    # set(): None keeps, masks restrict to some envs
+    sh.set_state(vel=np.zeros((E, N, 3), np.float32), env_mask=np.array([1, 0, 1], np.uint8))
+    g2 = _gpu_state(sh)
+    assert np.all(g2["vel"][0] == 0) and np.array_equal(g2["vel"][1], g["vel"][1]) and np.array_equal(g2["pos"], g["pos"])
+    # quaternion and matrix orientations
+    from scipy.spatial.transform import Rotation as R
+    q = R.from_euler("xyz", eul.reshape(-1, 3).astype(np.float64)).as_quat().astype(np.float32).reshape(E, N, 4)
+    sh.set_state(ori=q)
+    assert np.abs(_gpu_state(sh)["quat"] - q.astype(np.float64)).max() == 0
+    m = R.from_euler("xyz", eul.reshape(-1, 3).astype(np.float64)).as_matrix().astype(np.float32).reshape(E, N, 3, 3)
+    sh.set_state(ori=m)
+    assert _quat_err(_gpu_state(sh)["quat"], sw.quat) < 1e-6
+
+
+@pytest.mark.parametrize("atype", ["set_target_vel", "set_target_pos", "set_target_accel", "set_target_ori",
+                                   "set_control", "set_speeds", None])
+@pytest.mark.parametrize("E,N", [(5, 3), (3, 12), (6, 64)])
+def test_step_parity_200_steps(atype, E, N):
+    sh, sw, pos0 = _mk(E, N, atype)
+    acts = ActionStream(atype, E, N, pos0, seed=7) if atype else None
+    obs = torch.zeros(E, N, sh.D, device="cuda:0")
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    dense = torch.zeros(E, N, N, device="cuda:0")
+    for t in range(200):
+        a = acts(t) if acts else None
+        sh.step(None if a is None else torch.from_numpy(a).cuda(), atype, obs_out=obs, adj_out=adj, comm_range=2.5)
+        sw.step(a, atype)
+        if t % 50 == 49 or t < 3:
+            _compare(sh, sw, 1e-6, "%s E%d N%d t=%d" % (atype, E, N, t))
+            if atype:
+                np.testing.assert_allclose(sh.view(sh.rpm).cpu().numpy(), sw.speeds, rtol=2e-6, atol=1e-2)
+            # adjacency from the GPU's own positions must equal the oracle's calc_A on those positions
+            sh.adjacency_expand(adj, dense)
+            p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
+            want = np.stack([oracle.adjacency(p32[e], 2.5) for e in range(E)])
+            assert np.array_equal(dense.cpu().numpy(), want)
+            o = obs.cpu().numpy()
+            np.testing.assert_array_equal(o[..., :3], p32)
+            np.testing.assert_array_equal(o[..., 3:], sh.view(sh.vel).cpu().numpy().astype(np.float32))
+
+
+@pytest.mark.parametrize("atype", ["set_target_vel", "set_target_pos", "set_speeds"])
+def test_north_star_tolerance_1000_steps(atype):
+    """pos/ori/vel within 1e-4 abs over 1000 steps (free flight: PID holds the swarm aloft; the
+    set_speeds case runs with contact disabled so that tumbling ground impacts do not enter)."""
+    E, N = 4, 64
+    sh, sw, pos0 = _mk(E, N, atype)
+    if atype == "set_speeds":
+        import mrsgym_amd
+        p = mrsgym_amd.default_params(); p.enable_contact = 0; p.ground_z = -1e9
+        sh.set_params(p)
+        sw.p.enable_contact = 0; sw.p.ground_z = -1e9
+    acts = ActionStream(atype, E, N, pos0, seed=11)
+    worst = {}
+    for t in range(1000):
+        a = acts(t)
+        sh.step(torch.from_numpy(a).cuda(), atype)
+        sw.step(a, atype)
+        if t % 100 == 99:
+            errs = _compare(sh, sw, 1e-4, "%s t=%d" % (atype, t))
+            worst = {k: max(v, worst.get(k, 0)) for k, v in errs.items()}
+    print("north-star parity", atype, worst)
+    if atype != "set_speeds":
+        assert sw.pos[..., 2].min() > 0.7, "scenario was meant to stay in free flight"
+
+
+def test_adjacency_golden_bit_exact(golden_dir):
+    import mrsgym_amd
+    d = np.load(os.path.join(golden_dir, "F3_adjacency.npz"))
+    n = 0
+    for k in d.files:
+        if not k.endswith("_pos"):
+            continue
+        key = k[:-4]
+        R = float(key.split("_R")[1].replace("p", "."))
+        pos = d[k]
+        N = pos.shape[0]
+        sh = mrsgym_amd.SwarmShard(1, N, "cuda:0")
+        sh.set_state(pos=pos[None])
+        adj = torch.zeros(1, N, sh.W, dtype=torch.int64, device="cuda:0")
+        dense = torch.zeros(1, N, N, device="cuda:0")
+        sh.adjacency(adj, R)
+        sh.adjacency_expand(adj, dense)
+        assert np.array_equal(dense[0].cpu().numpy().astype(np.uint8), d[key + "_A"]), key
+        n += 1
+    assert n >= 20
+    # planted near-threshold pairs, each pair its own 2-agent env
+    for Rk in ("2p5", "5p0", "0p7"):
+        a, b, want = d["pairs_R%s_a" % Rk], d["pairs_R%s_b" % Rk], d["pairs_R%s_adj" % Rk]
+        P = len(a)
+        sh = mrsgym_amd.SwarmShard(P, 2, "cuda:0")
+        sh.set_state(pos=np.stack([a, b], 1))
+        adj = torch.zeros(P, 2, 1, dtype=torch.int64, device="cuda:0")
+        sh.adjacency(adj, float(Rk.replace("p", ".")))
+        got = (adj[:, 0, 0].cpu().numpy() >> 1) & 1
+        assert np.array_equal(got.astype(np.uint8), want), Rk
+
+
+def test_reference_trajectories_F6(golden_dir):
+    """The reference's own MRS.step() trajectories (fake-bullet harness), teacher-forced on the GPU."""
+    import glob
+    import mrsgym_amd
+    for path in sorted(glob.glob(os.path.join(golden_dir, "F6_step_N*.npz"))):
+        d = np.load(path)
+        name = os.path.basename(path)[8:-4]
+        N, atype = int(name.split("_")[0][1:]), name.split("_", 1)[1]
+        D = int(d["D"])
+        fields = ("pos", "vel") if D == 6 else ("pos", "ori", "vel", "angvel")
+        sh = mrsgym_amd.SwarmShard(1, N, "cuda:0", obs_fields=fields)
+        z = np.zeros((1, N, 3), np.float32)
+        sh.set_state(pos=d["start"][None], ori=d["ori0"][None], vel=z, angvel=z)
+        obs = torch.zeros(1, N, D, device="cuda:0")
+        adj = torch.zeros(1, N, sh.W, dtype=torch.int64, device="cuda:0")
+        dense = torch.zeros(1, N, N, device="cuda:0")
+        for t in range(d["actions"].shape[0]):
+            sh.step(torch.from_numpy(d["actions"][t][None]).cuda(), atype, obs_out=obs, adj_out=adj,
+                    comm_range=float(d["COMM_RANGE"]))
+            g = _gpu_state(sh)
+            s = d["state"][t]
+            st = np.concatenate([g["pos"][0], g["quat"][0], g["vel"][0], g["angvel"][0]], 1)
+            assert np.abs(st - s).max() < 5e-6, (name, t, np.abs(st - s).max())
+            sh.set_state_f64(pos=s[None, :, 0:3], quat=s[None, :, 3:7], vel=s[None, :, 7:10], angvel=s[None, :, 10:13])
+        # final step's outputs, from the teacher-forced state
+        sh.observe(obs)
+        np.testing.assert_allclose(obs[0].cpu().numpy(), d["X"][-1][0], rtol=0, atol=1e-6)
+        sh.adjacency(adj, float(d["COMM_RANGE"]))
+        sh.adjacency_expand(adj, dense)
+        assert np.array_equal(dense[0].cpu().numpy().astype(np.uint8), d["A"][-1][0]), name
+
+
+def test_nan_action_skips_env_and_flags_it():
+    import mrsgym_amd
+    E, N = 4, 64
+    sh, sw, pos0 = _mk(E, N, "set_target_vel")
+    a = np.zeros((E, N, 3), np.float32)
+    a[2, 17, 1] = np.nan
+    before = _gpu_state(sh)
+    sh.step(torch.from_numpy(a).cuda(), "set_target_vel")
+    after = _gpu_state(sh)
+    st = sh.status.cpu().numpy()
+    assert list(st) == [0, 0, 1, 0]                              # MRS.py:247-248 -> raised lazily by the host
+    assert np.array_equal(after["pos"][2], before["pos"][2])     # that env did not step
+    assert not np.array_equal(after["pos"][1], before["pos"][1])
+
+
+def test_unknown_action_type_raises_attribute_error():
+    sh, sw, _ = _mk(1, 3, None)
+    with pytest.raises(AttributeError):                          # Environment.py:92 getattr
+        sh.step(torch.zeros(1, 3, 3, device="cuda:0"), "set_force")
+
+
+def test_large_n_and_ragged_blocks():
+    # N=256 (4 waves per env), N=300 (1024-thread workgroup), N=1 and E not a multiple of envs-per-block
+    for E, N, atype in [(3, 256, "set_control"), (2, 300, "set_target_vel"), (7, 1, "set_target_pos"), (9, 100, "set_speeds")]:
+        sh, sw, pos0 = _mk(E, N, atype)
+        acts = ActionStream(atype, E, N, pos0, seed=3)
+        adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+        dense = torch.zeros(E, N, N, device="cuda:0")
+        for t in range(30):
+            a = acts(t)
+            sh.step(torch.from_numpy(a).cuda(), atype, adj_out=adj, comm_range=5.0)
+            sw.step(a, atype)
+        _compare(sh, sw, 1e-7, "E%d N%d %s" % (E, N, atype))
+        sh.adjacency_expand(adj, dense)
+        p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
+        want = np.stack([oracle.adjacency(p32[e], 5.0) for e in range(E)])
+        assert np.array_equal(dense.cpu().numpy(), want)
+    sh, sw, _ = _mk(2, 8, None)
+    adj = torch.zeros(2, 8, 1, dtype=torch.int64, device="cuda:0")
+    sh.adjacency(adj, float("inf"))                              # MRS.py:118-119 ones - eye
+    assert np.array_equal(adj[:, :, 0].cpu().numpy(), np.broadcast_to(0xFF ^ (1 << np.arange(8)), (2, 8)))
+
+
+def test_touchdown_and_rest_match_oracle():
+    import mrsgym_amd
+    E, N = 2, 5
+    rng = np.random.default_rng(9)
+    pos = np.concatenate([rng.uniform(-1, 1, (E, N, 2)) * 3, rng.uniform(0.55, 0.9, (E, N, 1))], -1).astype(np.float32)
+    eul = (rng.uniform(-1, 1, (E, N, 3)) * [0.6, 0.6, 3]).astype(np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    sw = oracle.OracleSwarm(E, N)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z.astype(np.float64), angvel=z.astype(np.float64))
+    for t in range(300):
+        sh.step(None, None)
+        sw.step(None, None)
+    # stated, looser tolerance for contact (the active set can flip on 1e-16 differences)
+    _compare(sh, sw, 1e-3, "touchdown")
+    g = _gpu_state(sh)
+    assert g["pos"][..., 2].max() < 0.58 and np.abs(g["vel"]).max() < 0.05
+
+
+def test_spawn_properties():
+    import mrsgym_amd
+    for N in (3, 12, 32):
+        E = 16
+        sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+        sh.spawn(seed=1234, agent_radius=0.3)
+        g = _gpu_state(sh)
+        assert int(sh.status.cpu().sum()) == 0
+        p = g["pos"]
+        assert (np.hypot(p[..., 0], p[..., 1]) <= 1 + 1e-6).all() and (p[..., 2] >= 1).all() and (p[..., 2] <= 3).all()
+        d = np.linalg.norm(p[:, :, None] - p[:, None], axis=-1) + np.eye(N) * 1e9
+        assert d.min() >= 0.6 - 1e-6                         # MRS.py:137 2*AGENT_RADIUS
+        e = np.array([oracle.quat_to_euler(q) for q in g["quat"].reshape(-1, 4)])
+        assert np.abs(e[:, :2]).max() < 1e-12 and (np.abs(e[:, 2]) <= np.pi / 2 + 1e-9).all()
+        assert np.all(g["vel"] == 0) and np.all(g["angvel"] == 0)
+        # sharding invariance: envs 8..15 spawned alone with env_index_base=8 are identical
+        sh2 = mrsgym_amd.SwarmShard(8, N, "cuda:0")
+        sh2.spawn(seed=1234, env_index_base=8, agent_radius=0.3)
+        assert np.array_equal(_gpu_state(sh2)["pos"], p[8:])
+    # N=64 cannot fit the default volume: bounded rounds, flagged, no hang
+    sh = mrsgym_amd.SwarmShard(2, 64, "cuda:0")
+    sh.spawn(seed=1, agent_radius=0.3, max_rounds=50)
+    assert (sh.status.cpu().numpy() & 2).all()
+
+
+def test_env_sharding_is_bitwise():
+    """E envs on one shard == the same envs split over two shards (multi-GPU correctness)."""
+    import mrsgym_amd
+    E, N, atype = 8, 64, "set_target_vel"
+    pos, eul = grid_spawn(E, N, seed=2)
+    z = np.zeros((E, N, 3), np.float32)
+    full = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    full.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    halves = []
+    for s in range(2):
+        h = mrsgym_amd.SwarmShard(E // 2, N, "cuda:0")
+        sl = slice(s * E // 2, (s + 1) * E // 2)
+        h.set_state(pos=pos[sl], ori=eul[sl], vel=z[sl], angvel=z[sl])
+        halves.append(h)
+    acts = ActionStream(atype, E, N, pos, seed=5)
+    for t in range(100):
+        a = torch.from_numpy(acts(t)).cuda()
+        full.step(a, atype)
+        for s, h in enumerate(halves):
+            h.step(a[s * E // 2:(s + 1) * E // 2].contiguous(), atype)
+    f = _gpu_state(full)
+    for k in f:
+        got = np.concatenate([_gpu_state(h)[k] for h in halves])
+        assert np.array_equal(got, f[k]), k
