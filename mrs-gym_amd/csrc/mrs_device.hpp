@@ -18,6 +18,33 @@ namespace mrs {
 
 constexpr double kPi = 3.14159265358979323846;
 
+// float32 operations that must round exactly like the reference's numpy/torch float32 arithmetic.
+// hipcc contracts a*b+c into an FMA by default and ROCm's __fmul_rn/__fadd_rn are plain operators,
+// so each helper switches contraction off for its own statement (the flag travels with the
+// instruction through inlining).  f32fma is the one place an FMA is wanted (torch's norm kernel).
+MRS_DEV float f32mul(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+MRS_DEV float f32add(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+MRS_DEV float f32sub(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+MRS_DEV float f32div(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a / b; // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+}
+MRS_DEV float f32sqrt(float a) { return __fsqrt_rn(a); }
+MRS_DEV float f32fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 struct V3 {
     double x, y, z;
 };
@@ -209,19 +236,19 @@ MRS_DEV void accel_control(const MrsParams &P, Pid &s, V3 ta_in, const M3 &R, co
 MRS_DEV V3 vel_control_accel(const MrsParams &P, Pid &s, const Observed &o, float tvx, float tvy, float tvz)
 {
     const float dt32 = (float)P.ctrl_dt;
-    const float ex = __fsub_rn(tvx, o.vx), ey = __fsub_rn(tvy, o.vy), ez = __fsub_rn(tvz, o.vz); // :54
+    const float ex = f32sub(tvx, o.vx), ey = f32sub(tvy, o.vy), ez = f32sub(tvz, o.vz); // :54
     if (isnan(s.lvx)) { s.lvx = ex; s.lvy = ey; s.lvz = ez; s.dvx = s.dvy = s.dvz = 0.; }       // :55-57
     if (isnan(s.ltx)) { s.ltx = tvx; s.lty = tvy; s.ltz = tvz; }                                // :58-59
     // :62 d = (((e - e_last) - (tv - tv_last)) / DT) * 0.5 + d * 0.5
-    const float hx = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ex, s.lvx), __fsub_rn(tvx, s.ltx)), dt32), 0.5f);
-    const float hy = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ey, s.lvy), __fsub_rn(tvy, s.lty)), dt32), 0.5f);
-    const float hz = __fmul_rn(__fdiv_rn(__fsub_rn(__fsub_rn(ez, s.lvz), __fsub_rn(tvz, s.ltz)), dt32), 0.5f);
+    const float hx = f32mul(f32div(f32sub(f32sub(ex, s.lvx), f32sub(tvx, s.ltx)), dt32), 0.5f);
+    const float hy = f32mul(f32div(f32sub(f32sub(ey, s.lvy), f32sub(tvy, s.lty)), dt32), 0.5f);
+    const float hz = f32mul(f32div(f32sub(f32sub(ez, s.lvz), f32sub(tvz, s.ltz)), dt32), 0.5f);
     s.dvx = (double)hx + s.dvx * 0.5; s.dvy = (double)hy + s.dvy * 0.5; s.dvz = (double)hz + s.dvz * 0.5;
     s.lvx = ex; s.lvy = ey; s.lvz = ez;       // :64
     s.ltx = tvx; s.lty = tvy; s.ltz = tvz;    // :65
-    s.ivx = s.ivx + (double)__fmul_rn(ex, dt32); // :66
-    s.ivy = s.ivy + (double)__fmul_rn(ey, dt32);
-    s.ivz = s.ivz + (double)__fmul_rn(ez, dt32);
+    s.ivx = s.ivx + (double)f32mul(ex, dt32); // :66
+    s.ivy = s.ivy + (double)f32mul(ey, dt32);
+    s.ivz = s.ivz + (double)f32mul(ez, dt32);
     // :67-69 P=3 I=.1 D=1
     return v3(3. * (double)ex + .1 * s.ivx + 1. * s.dvx, 3. * (double)ey + .1 * s.ivy + 1. * s.dvy,
               3. * (double)ez + .1 * s.ivz + 1. * s.dvz);
@@ -231,10 +258,10 @@ MRS_DEV V3 vel_control_accel(const MrsParams &P, Pid &s, const Observed &o, floa
 MRS_DEV V3 pos_control_accel(const MrsParams &P, Pid &s, const Observed &o, float tpx, float tpy, float tpz)
 {
     const float dt32 = (float)P.ctrl_dt;
-    const float ex = __fsub_rn(tpx, o.px), ey = __fsub_rn(tpy, o.py), ez = __fsub_rn(tpz, o.pz); // :40
-    s.ipx = s.ipx + (double)__fmul_rn(ex, dt32); // :44
-    s.ipy = s.ipy + (double)__fmul_rn(ey, dt32);
-    s.ipz = s.ipz + (double)__fmul_rn(ez, dt32);
+    const float ex = f32sub(tpx, o.px), ey = f32sub(tpy, o.py), ez = f32sub(tpz, o.pz); // :40
+    s.ipx = s.ipx + (double)f32mul(ex, dt32); // :44
+    s.ipy = s.ipy + (double)f32mul(ey, dt32);
+    s.ipz = s.ipz + (double)f32mul(ez, dt32);
     // :45-47 P=1.5 I=.001 D=1 with d_pos_e = 0 - vel
     return v3(1.5 * (double)ex + .001 * s.ipx + 1. * (0.0 - (double)o.vx),
               1.5 * (double)ey + .001 * s.ipy + 1. * (0.0 - (double)o.vy),
@@ -257,10 +284,10 @@ MRS_DEV void nnls2(double p, double q, double &x, double &y)
 // scipy splits into two independent 2-variable problems {0,2} and {1,3}, solved in closed form.
 MRS_DEV void set_control(const MrsParams &P, float c0, float c1, float c2, float c3, double rpm[4])
 {
-    const double thrust = (double)__fmul_rn(c0, (float)P.mass);   // :27-30 float32 tensor * python float
-    const double roll = (double)__fmul_rn(c1, (float)P.ixx_file);
-    const double pitch = (double)__fmul_rn(c2, (float)P.iyy_file);
-    const double yaw = (double)__fmul_rn(c3, (float)P.izz_file);
+    const double thrust = (double)f32mul(c0, (float)P.mass);   // :27-30 float32 tensor * python float
+    const double roll = (double)f32mul(c1, (float)P.ixx_file);
+    const double pitch = (double)f32mul(c2, (float)P.iyy_file);
+    const double yaw = (double)f32mul(c3, (float)P.izz_file);
     const double c = 0.70710678118654752440;
     const double B0 = thrust * (1 / P.kf), B1 = roll * (1 / (P.kf * P.arm)), B2 = pitch * (1 / (P.kf * P.arm)),
                  B3 = yaw * (1 / P.km); // :166, :202
@@ -284,16 +311,16 @@ MRS_DEV void set_control(const MrsParams &P, float c0, float c1, float c2, float
 // (rx,ry,dz) = other - self.
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
 {
-    const float dxy = __fsqrt_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry))); // np.linalg.norm(rel[:2])
+    const float dxy = f32sqrt(f32add(f32mul(rx, rx), f32mul(ry, ry))); // np.linalg.norm(rel[:2])
     float f = 0.f;
     if (dz > 0.f && dxy < 10.f) {
-        const float rc = __fdiv_rn(1.0f, __fmul_rn(4.0f, dz));   // PropRadius/(4 dz) = reciprocal()*scalar
-        const float q = __fmul_rn(rc, pr32);
-        const float alpha = __fmul_rn(dw1, __fmul_rn(q, q));
-        const float beta = __fadd_rn(__fmul_rn(dw2, dz), dw3);
-        const float t = __fmul_rn(__fdiv_rn(1.0f, beta), dxy);   // np.float32 / tensor -> reciprocal()*other
-        const float ex = expf(__fmul_rn(-.5f, __fmul_rn(t, t)));
-        f = -__fmul_rn(alpha, ex);
+        const float rc = f32div(1.0f, f32mul(4.0f, dz));   // PropRadius/(4 dz) = reciprocal()*scalar
+        const float q = f32mul(rc, pr32);
+        const float alpha = f32mul(dw1, f32mul(q, q));
+        const float beta = f32add(f32mul(dw2, dz), dw3);
+        const float t = f32mul(f32div(1.0f, beta), dxy);   // np.float32 / tensor -> reciprocal()*other
+        const float ex = expf(f32mul(-.5f, f32mul(t, t)));
+        f = -f32mul(alpha, ex);
     }
     return f;
 }

@@ -79,8 +79,8 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *t
         for (int jj = 0; jj < jn; ++jj) {
             const int j = wd * 64 + jj;
             const float4 pj = tile_env[j];
-            const float dx = __fsub_rn(me.x, pj.x), dy = __fsub_rn(me.y, pj.y), dz = __fsub_rn(me.z, pj.z);
-            const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+            const float dx = f32sub(me.x, pj.x), dy = f32sub(me.y, pj.y), dz = f32sub(me.z, pj.z);
+            const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
             const bool adj = (A.comm_inf ? true : (d2 <= A.d2_thresh)) && (j != i);
             bits |= (uint64_t)adj << jj;
         }
@@ -183,14 +183,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
                 float t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float sq = __fmul_rn(s32[k], s32[k]);
-                    F[k] = (double)__fmul_rn(sq, (float)P.kf);
-                    t[k] = __fmul_rn(sq, (float)P.km);
+                    const float sq = f32mul(s32[k], s32[k]);
+                    F[k] = (double)f32mul(sq, (float)P.kf);
+                    t[k] = f32mul(sq, (float)P.km);
                 }
-                zt = (double)__fadd_rn(__fsub_rn(__fadd_rn(-t[0], t[1]), t[2]), t[3]);
+                zt = (double)f32add(f32sub(f32add(-t[0], t[1]), t[2]), t[3]);
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fdiv_rn(__fmul_rn((float)(2 * kPi), s32[k]), 60.f));
+                for (int k = 0; k < 4; ++k) acc = f32add(acc, f32div(f32mul((float)(2 * kPi), s32[k]), 60.f));
                 sumw = (double)acc;
             } else {
                 double t[4];
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
                 const double ratio = P.prop_radius / (4 * h);
                 double g;
                 if (ACT == MRS_ACT_SET_SPEEDS) {
-                    const float sq = __fmul_rn(s32[k], s32[k]);
-                    g = (double)__fmul_rn(__fmul_rn(sq, (float)P.kf), (float)P.gnd_eff_coeff) * (ratio * ratio);
+                    const float sq = f32mul(s32[k], s32[k]);
+                    g = (double)f32mul(f32mul(sq, (float)P.kf), (float)P.gnd_eff_coeff) * (ratio * ratio);
                 } else {
                     g = ((rpm[k] * rpm[k]) * P.kf) * P.gnd_eff_coeff * (ratio * ratio);
                 }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
                 double acc = 0;
                 for (int j = 0; j < A.N; ++j) {
                     const float4 pj = tile_env[j];
-                    const float f = downwash_pair(__fsub_rn(pj.x, ob.px), __fsub_rn(pj.y, ob.py), __fsub_rn(pj.z, ob.pz), pr32, dw1, dw2, dw3);
+                    const float f = downwash_pair(f32sub(pj.x, ob.px), f32sub(pj.y, ob.py), f32sub(pj.z, ob.pz), pr32, dw1, dw2, dw3);
                     acc += (double)f;
                 }
                 fb.z += acc;

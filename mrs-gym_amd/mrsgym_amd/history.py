@@ -1,0 +1,56 @@
+"""K_HOPS history stack of the reference (the deques of MRS.py:87-114) as a device ring.
+
+The reference keeps `deque`s of the last K+1 observation / adjacency tensors, newest first, and
+re-stacks them every step.  Here the K+1 newest slices always occupy CONSECUTIVE slots
+[head, head+K] of one buffer of L >> K+1 slots, so the stacked result is a zero-copy view and the
+step kernel writes the newest slice straight into slot `head`.  The window slides towards slot 0;
+when it gets there the K surviving slices are moved to the far end (once every L-K steps).
+
+Padding rules pinned by tests/golden/F4: X is padded with copies of the first slice (MRS.py:92-93),
+A with zeros (MRS.py:107-108).
+"""
+import torch
+
+
+class HistoryRing:
+    def __init__(self, k_hops, slice_shape, dtype, device, slots=0, pad="copy"):
+        self.K = int(k_hops)
+        self.L = max(int(slots) if slots else 8 * (self.K + 1), 2 * (self.K + 1))
+        self.pad = pad
+        self.buf = torch.zeros((self.L,) + tuple(slice_shape), dtype=dtype, device=device)
+        self.clear()
+
+    def clear(self):
+        """deque([]) (MRS.py:185-186)."""
+        self.head = self.L - (self.K + 1)
+        self.count = 0
+        if self.pad == "zero":
+            self.buf[self.head:].zero_()
+
+    def next_slot(self):
+        """Slot the newest slice must be written to (appendleft + pop, MRS.py:89-91 / :104-106)."""
+        if self.count > 0:
+            if self.head == 0:
+                new_head = self.L - (self.K + 1)
+                if self.K > 0:
+                    self.buf[new_head + 1:new_head + 1 + self.K].copy_(self.buf[0:self.K].clone())
+                self.head = new_head
+            else:
+                self.head -= 1
+        return self.head
+
+    def committed(self):
+        """Call after the newest slice has been written (possibly asynchronously, same stream)."""
+        if self.count == 0 and self.K > 0:
+            if self.pad == "copy":
+                self.buf[self.head + 1:self.head + 1 + self.K] = self.buf[self.head].unsqueeze(0)
+            else:
+                self.buf[self.head + 1:self.head + 1 + self.K].zero_()
+        self.count = min(self.count + 1, self.K + 1)
+
+    def newest(self):
+        return self.buf[self.head]
+
+    def window(self):
+        """(K+1, ...) newest first, a view."""
+        return self.buf[self.head:self.head + self.K + 1]

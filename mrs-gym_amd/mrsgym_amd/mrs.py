@@ -1,0 +1,460 @@
+"""Host-side mirror of the reference's Gym surface: class MRS ('mrs-v0'), make().
+
+Same names, kwargs, return conventions and error behaviour as mrsgym/MRS.py (cited per method), with
+every per-agent Python loop of the reference replaced by one C-ABI call into the HIP library.
+Extensions (all optional, defaults reproduce the reference's shapes): N_ENVS, DEVICE, OBS,
+A_FORMAT, SEED, RESET_CONTROLLERS, CHECK_NAN, ENV_INDEX_BASE.  With N_ENVS = E > 1 every tensor
+gains a leading E axis: Xk (E,K+1,N,D), Ak (E,K+1,N,N), actions (E,N,ACTION_DIM).
+"""
+import math
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import native
+from .facade import Environment, QuadView, StateFnCompiler
+from .history import HistoryRing
+
+try:  # gym / gymnasium are optional (absent in the build image)
+    import gym as _gym  # type: ignore
+    from gym.spaces import Box  # type: ignore
+    _EnvBase = _gym.Env
+except Exception:  # pragma: no cover
+    try:
+        import gymnasium as _gym  # type: ignore
+        from gymnasium.spaces import Box  # type: ignore
+        _EnvBase = _gym.Env
+    except Exception:
+        _gym = None
+        _EnvBase = object
+
+        class Box:  # minimal stand-in: low/high/shape/dtype, sample()
+            def __init__(self, low, high, dtype=np.float32):
+                self.low, self.high = np.asarray(low), np.asarray(high)
+                self.shape, self.dtype = self.low.shape, dtype
+
+            def sample(self):
+                lo = np.where(np.isfinite(self.low), self.low, -1.0)
+                hi = np.where(np.isfinite(self.high), self.high, 1.0)
+                return np.random.uniform(lo, hi).astype(self.dtype)
+
+            def contains(self, x):
+                x = np.asarray(x)
+                return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class MRS(_EnvBase):
+
+    metadata = {'render.modes': ['headless', 'bullet']}
+
+    # MRS.__init__, MRS.py:21-66
+    def __init__(self, state_fn=None, reward_fn=None, done_fn=None, info_fn=None, update_fn=None, start_fn=None,
+                 env='simple', **kwargs):
+        if _EnvBase is not object:
+            super(MRS, self).__init__()
+        # Constants (MRS.py:24-34)
+        self.N_AGENTS = 1
+        self.K_HOPS = 0
+        self.STATE_SIZE = 0
+        self.ACTION_DIM = 0
+        self.AGENT_RADIUS = 0.3
+        self.COMM_RANGE = float('inf')
+        self.RETURN_A = None          # reference: declared, never read (A is always returned). None = that.
+        self.RETURN_EVENTS = False
+        self.ACTION_TYPE = "set_target_vel"
+        self.HEADLESS = False
+        self.MAX_TIMESTEPS = float('inf')
+        # extensions
+        self.N_ENVS = 1
+        self.DEVICE = "cuda"
+        self.OBS = None               # explicit fused observation spec, e.g. ("pos", "vel")
+        self.A_FORMAT = "dense"       # "dense": float32 0/1 (reference) | "packed": int64 bit rows (E,K+1,N,ceil(N/64))
+        self.SEED = 0
+        self.ENV_INDEX_BASE = 0       # global index of this shard's first env (multi-GPU)
+        self.RESET_CONTROLLERS = False  # reference: PID integrators survive reset() (QuadControl objects persist)
+        self.CHECK_NAN = None         # "sync" | "lazy" | "off"; None = sync for N_ENVS==1 else lazy
+        self.HISTORY_SLOTS = 0        # ring length; 0 = 8*(K_HOPS+1)
+        # BulletSim constants (BulletSim.py:11-15); DT/GRAVITY reach the world only, never the controller
+        self.REAL_TIME = False
+        self.GRAVITY = 9.81
+        self.DT = 0.01
+        self.set_constants(kwargs)
+        # Inputs (MRS.py:37-42)
+        self.state_fn = state_fn
+        self.reward_fn = reward_fn if (reward_fn is not None) else (lambda **kwargs: 0.0)
+        self.done_fn = done_fn if (done_fn is not None) else (lambda **kwargs: kwargs["steps_since_reset"] >= self.MAX_TIMESTEPS)
+        self.info_fn = info_fn if (info_fn is not None) else (lambda **kwargs: {})
+        self.update_fn = update_fn
+        self.start_fn = start_fn
+        if not isinstance(env, str):
+            raise NotImplementedError("only env='simple' (N quadcopters over the ground box, EnvCreator.py:7-13) is "
+                                      "on the accelerated path; custom Environment objects are out of scope")
+        if env != 'simple':
+            raise ValueError("unknown envtype %r" % (env,))
+        self.device = torch.device(self.DEVICE)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        # sim handle (BulletSim.__init__/setup) + env_generator('simple')
+        params = native.default_params()
+        params.gravity, params.dt = float(self.GRAVITY), float(self.DT)
+        self.sim = types.SimpleNamespace(DT=float(self.DT), GRAVITY=float(self.GRAVITY), REAL_TIME=bool(self.REAL_TIME),
+                                         HEADLESS=bool(self.HEADLESS), id=0, params=params)
+        self.shard = native.SwarmShard(self.N_ENVS, self.N_AGENTS, self.device, params=params)
+        self.env = Environment(self)
+        # Constants that depend on other constants (MRS.py:51-57; the size expression keeps upstream's precedence)
+        n_obs = self.K_HOPS + 1 * self.N_AGENTS * self.STATE_SIZE
+        self.observation_space = Box(np.full((n_obs), -np.inf, dtype=np.float32), np.full((n_obs), np.inf, dtype=np.float32))
+        self.action_space = Box(np.tile(np.array([9.81 - 1, -1., -1., -1.]), self.N_AGENTS),
+                                np.tile(np.array([9.81 + 1, 1., 1., 1.]), self.N_AGENTS))
+        self.START_POS = None         # None = default_spawn_dist() semantics on the device (MRS.py:69-78)
+        self.START_ORI = torch.tensor([0, 0, -np.pi / 2, 0, 0, np.pi / 2])
+        if len(self.START_ORI.shape) == 1:
+            self.START_ORI = self.START_ORI.expand(self.N_AGENTS, -1)
+        self.set_constants(kwargs)
+        # observation plumbing
+        self._obs = StateFnCompiler(self)
+        self.STATE_DIM = None
+        # Data (MRS.py:59-65)
+        self.steps_since_reset = 0
+        self.last_action = None
+        self.last_obs = None
+        self.last_loop_time = time.monotonic()
+        self.is_initialised = False
+        self._resets = 0
+        self._alloc_history()
+        self.reset()
+
+    # ------------------------------------------------------------------ helpers
+    def set_constants(self, kwargs):  # MRS.py:81-84
+        for name, val in kwargs.items():
+            if name in self.__dict__:
+                self.__dict__[name] = val
+
+    @property
+    def E(self):
+        return self.N_ENVS
+
+    def _squeeze(self, t):
+        """(E, ...) -> (...) when N_ENVS == 1 so that shapes equal the reference's."""
+        return t[0] if self.N_ENVS == 1 else t
+
+    def _alloc_history(self):
+        E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
+        self._Xring = None            # allocated once D is known (StateFnCompiler)
+        self._Apacked = HistoryRing(self.K_HOPS, (E, N, W), torch.int64, self.device, self.HISTORY_SLOTS, pad="zero")
+        self._Adense = None
+        if self.A_FORMAT == "dense":
+            self._Adense = HistoryRing(self.K_HOPS, (E, N, N), torch.float32, self.device, self.HISTORY_SLOTS, pad="zero")
+
+    def _ensure_xbuf(self, D):
+        if self._Xring is None or self._Xring.buf.shape[-1] != D:
+            self._Xring = HistoryRing(self.K_HOPS, (self.N_ENVS, self.N_AGENTS, D), torch.float32, self.device,
+                                      self.HISTORY_SLOTS, pad="copy")
+            self.STATE_DIM = D
+
+    # ------------------------------------------------------------------ observation / adjacency stacks
+    def calc_Xk(self):  # MRS.py:87-95
+        if not self._obs._compiled:
+            self._obs.compile()
+        if self._Xring is None:      # generic state_fn: D is only known after one evaluation
+            X = self._obs.evaluate(self.state_fn)
+            self._ensure_xbuf(X.shape[-1])
+        self._obs.write_into(self._Xring.buf[self._Xring.next_slot()])
+        self._Xring.committed()
+        return self.get_Xk()
+
+    def get_Xk(self):  # MRS.py:98-99  Xk: K+1 x N x D  (E x K+1 x N x D)
+        return self._squeeze(self._Xring.window().permute(1, 0, 2, 3))
+
+    def calc_Ak(self):  # MRS.py:102-110
+        slot = self._Apacked.next_slot()
+        self.shard.adjacency(self._Apacked.buf[slot], self.COMM_RANGE)
+        self._Apacked.committed()
+        self._expand_newest_A()
+        return self.get_Ak()
+
+    def _expand_newest_A(self):
+        if self._Adense is not None:
+            slot = self._Adense.next_slot()
+            self.shard.adjacency_expand(self._Apacked.newest(), self._Adense.buf[slot])
+            self._Adense.committed()
+
+    def get_Ak(self):  # MRS.py:113-114  Ak: K+1 x N x N, missing slots are zeros (MRS.py:107-108)
+        ring = self._Adense if self._Adense is not None else self._Apacked
+        return self._squeeze(ring.window().permute(1, 0, 2, 3))
+
+    def calc_A(self):  # MRS.py:117-124  newest adjacency only, no history side effect
+        E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
+        packed = torch.zeros(E, N, W, dtype=torch.int64, device=self.device)
+        self.shard.adjacency(packed, self.COMM_RANGE)
+        if self.A_FORMAT != "dense":
+            return self._squeeze(packed)
+        dense = torch.zeros(E, N, N, dtype=torch.float32, device=self.device)
+        self.shard.adjacency_expand(packed, dense)
+        return self._squeeze(dense)
+
+    def _clear_history(self):  # self.X = deque([]); self.A = deque([])  (MRS.py:185-186)
+        for r in (self._Xring, self._Apacked, self._Adense):
+            if r is not None:
+                r.clear()
+
+    # ------------------------------------------------------------------ spawn
+    def default_spawn_dist(self):  # MRS.py:69-78 (the torch.distributions object, for callers that want it)
+        from torch.distributions import Normal, Uniform
+        from .util import CombinedDistribution, SphereTransform
+        from torch.distributions import TransformedDistribution
+        z = Uniform(low=1.0 * torch.ones(self.N_AGENTS, 1), high=3.0 * torch.ones(self.N_AGENTS, 1))
+        xy = TransformedDistribution(Normal(torch.zeros(self.N_AGENTS, 2), 1.0), [SphereTransform(radius=1.0, within=True)])
+        return CombinedDistribution([xy, z], mixer='cat', dim=1)
+
+    def get_relative_position(self, pos):  # MRS.py:166-170
+        N = pos.shape[-2]
+        return pos.unsqueeze(-2).expand(*pos.shape[:-2], N, N, 3) - pos.unsqueeze(-3).expand(*pos.shape[:-2], N, N, 3)
+
+    def generate_start_pos(self):  # MRS.py:127-154, host path for tensors / user distributions
+        E, N = self.N_ENVS, self.N_AGENTS
+        sp = self.START_POS
+        if isinstance(sp, torch.Tensor):
+            return sp if sp.dim() == 3 else sp.unsqueeze(0).expand(E, N, 3)
+        out = []
+        for _ in range(E):
+            startpos = sp.sample()
+            one = False
+            if len(startpos.shape) == 1:
+                startpos = torch.stack([sp.sample() for _ in range(N)], dim=0)
+                one = True
+            codist = self.get_relative_position(startpos).norm(dim=2)
+            codist.diagonal().fill_(float('inf'))
+            while torch.any(codist < 2 * self.AGENT_RADIUS):
+                collisions = codist < 2 * self.AGENT_RADIUS
+                idxs = []
+                while torch.sum(collisions) != 0:
+                    idx = torch.mode(torch.where(collisions)[0])[0]
+                    idxs.append(idx)
+                    collisions[idx, :] = 0
+                    collisions[:, idx] = 0
+                idxs = torch.tensor(idxs)
+                if one:
+                    for idx in idxs:
+                        startpos[idx, :] = sp.sample()
+                else:
+                    new = sp.sample()
+                    startpos[idxs, :] = new[idxs, :]
+                codist = self.get_relative_position(startpos).norm(dim=2)
+                codist.diagonal().fill_(float('inf'))
+            out.append(startpos)
+        return torch.stack(out, 0)
+
+    def generate_start_ori(self):  # MRS.py:157-161
+        so = torch.as_tensor(self.START_ORI)
+        if so.shape[-1] == 3:
+            return so
+        lo, hi = so[..., :3].to(torch.float32), so[..., 3:].to(torch.float32)
+        shape = (self.N_ENVS,) + tuple(lo.shape) if self.N_ENVS > 1 else tuple(lo.shape)
+        x = torch.rand(shape, device=self.device)
+        return x * (hi - lo).to(self.device) + lo.to(self.device)
+
+    def _default_spawn(self):
+        """START_POS=None: the reference's default_spawn_dist() + rejection, on the device (mrs_spawn)."""
+        so = torch.as_tensor(self.START_ORI, dtype=torch.float32)
+        if so.dim() == 2 and not bool((so == so[0]).all()):
+            return False
+        so = so.reshape(-1, so.shape[-1])[0]
+        if so.shape[0] == 3:
+            lo = hi = so.tolist()
+        else:
+            lo, hi = so[:3].tolist(), so[3:].tolist()
+        self._resets += 1
+        self.shard.status.zero_()
+        self.shard.spawn(seed=(int(self.SEED) << 20) + self._resets, env_index_base=self.ENV_INDEX_BASE,
+                         agent_radius=self.AGENT_RADIUS, ori_lo=lo, ori_hi=hi)
+        if int((self.shard.status & native.STATUS_SPAWN_FAIL).any()):
+            raise RuntimeError("default spawn: %d agents of radius %.2f do not fit the unit-disc x [1,3] m volume "
+                               "(the reference's generate_start_pos never terminates here, MRS.py:137-153); "
+                               "pass START_POS" % (self.N_AGENTS, self.AGENT_RADIUS))
+        return True
+
+    # ------------------------------------------------------------------ Gym API
+    def reset(self, pos=None, ori=None, vel=None, angvel=None):  # MRS.py:174-192
+        self.is_initialised = True
+        E, N = self.N_ENVS, self.N_AGENTS
+        spawned = False
+        if pos is None and self.START_POS is None:
+            # default_spawn_dist() + rejection on the device; also draws START_ORI when it is one shared range
+            spawned = self._default_spawn()
+            if not spawned:
+                saved, self.START_POS = self.START_POS, self.default_spawn_dist()
+                pos = self.generate_start_pos()
+                self.START_POS = saved
+        elif pos is None:
+            pos = self.generate_start_pos()
+        if ori is None and not spawned:
+            ori = self.generate_start_ori()
+            if ori.dim() == 2 and E > 1:
+                ori = ori.unsqueeze(0).expand(E, N, ori.shape[-1])
+        if vel is None:
+            vel = torch.zeros(E, N, 3)
+        if angvel is None:
+            angvel = torch.zeros(E, N, 3)
+        self.env.set_state(pos=pos, ori=ori, vel=vel, angvel=angvel)
+        if self.RESET_CONTROLLERS:
+            self.shard.pid_reset()
+        self._clear_history()
+        self.steps_since_reset = 0
+        if self.start_fn is not None:
+            self.start_fn(self)
+        Xk = self.calc_Xk()
+        self.last_obs = Xk
+        return Xk
+
+    def set(self, pos=None, ori=None, vel=None, angvel=None):  # MRS.py:196-205
+        self.env.set_state(pos=pos, ori=ori, vel=vel, angvel=angvel)
+        self._clear_history()
+        self.steps_since_reset = 0
+        if self.start_fn is not None:
+            self.start_fn(self)
+        Xk = self.calc_Xk()
+        self.last_obs = Xk
+        return Xk
+
+    def set_data(self, name, val):  # MRS.py:208-213
+        self.env.set_data(name, val)
+
+    def get_data(self, name):
+        return self.env.get_data(name)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):  # MRS.py:220-224: never raises
+        try:
+            self.check_errors()
+        except Exception:
+            pass
+
+    def render(self, mode='bullet', close=False):  # MRS.py:227-229
+        if close:
+            self.close()
+
+    def wait(self, dt=None):  # MRS.py:232-237
+        if dt is None:
+            dt = self.sim.DT
+        diff = time.monotonic() - self.last_loop_time
+        time.sleep(max(dt - diff, 0))
+
+    def check_errors(self):
+        """Raise what the reference raises synchronously inside step(): NaN actions (MRS.py:247-248)."""
+        st = self.shard.status
+        if int((st & native.STATUS_NAN_ACTION).any()):
+            bad = torch.nonzero(st & native.STATUS_NAN_ACTION).flatten().tolist()
+            st.bitwise_and_(~native.STATUS_NAN_ACTION)
+            raise Exception('The given action contains NaN (envs %s); those envs did not step' % bad)
+
+    def step(self, actions, ACTION_TYPE=None):  # MRS.py:240-277
+        E, N = self.N_ENVS, self.N_AGENTS
+        atype = None
+        if actions is not None:
+            actions = actions if isinstance(actions, torch.Tensor) else torch.tensor(np.asarray(actions))
+            actions = actions.detach()
+            if len(actions.shape) == 1:
+                actions = actions.reshape(self.N_AGENTS, self.ACTION_DIM)
+            mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
+            if mode == "sync" and bool(torch.isnan(actions).any()):
+                raise Exception('The given action contains NaN:\n %s' % str(actions))
+            self.last_action = actions
+            atype = ACTION_TYPE if ACTION_TYPE is not None else self.ACTION_TYPE
+            if atype not in native.ACT or atype is None:
+                raise AttributeError("'Quadcopter' object has no attribute %r" % (atype,))  # Environment.py:92
+        # env.set_actions + sim.step_sim + newest X slice + newest A rows: ONE fused launch
+        want_A = self.RETURN_A is None or bool(self.RETURN_A)
+        fused = self._obs.fused
+        xslot = self._Xring.next_slot()
+        aslot = self._Apacked.next_slot() if want_A else None
+        self.shard.step(actions, atype,
+                        obs_out=self._Xring.buf[xslot] if fused else None,
+                        adj_out=self._Apacked.buf[aslot] if want_A else None,
+                        comm_range=self.COMM_RANGE)
+        if not fused:
+            self._obs.write_into(self._Xring.buf[xslot])
+        self._Xring.committed()
+        Xk = self.get_Xk()
+        Ak = None
+        if want_A:
+            self._Apacked.committed()
+            self._expand_newest_A()
+            Ak = self.get_Ak()
+        mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
+        if mode == "lazy" and (self.steps_since_reset & 255) == 255:
+            self.check_errors()
+        # update function; draw_links is a GUI-only no-op here (MRS.py:259)
+        kw = dict(env=self.env, X=Xk, A=Ak, action=self.last_action, steps_since_reset=self.steps_since_reset)
+        if self.update_fn is not None:
+            self.update_fn(Xlast=self.last_obs, **kw)
+        reward = self.reward_fn(Xlast=self.last_obs, **kw)
+        self.last_obs = Xk
+        info = self.info_fn(Xlast=self.last_obs, **kw)   # sees Xlast == X, as upstream (MRS.py:264-266)
+        if want_A:
+            info["A"] = Ak
+        if self.RETURN_EVENTS:
+            info["keyboard_events"] = self.env.get_keyboard_events()
+            info["mouse_events"] = self.env.get_mouse_events()
+        done = self.done_fn(Xlast=self.last_obs, **kw)
+        self.last_loop_time = time.monotonic()
+        self.steps_since_reset += 1
+        return Xk, reward, done, info
+
+    def get_env(self):  # MRS.py:280-293
+        return self.env
+
+    def get_objects(self):
+        return self.env.objects
+
+    def get_agents(self):
+        return self.env.agents
+
+    def get_controlled(self):
+        return self.env.controlled
+
+    def get_object_dict(self):
+        return self.env.object_dict
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        return dict(shard=self.shard.state_dict(), steps_since_reset=self.steps_since_reset)
+
+    def load_state_dict(self, sd):
+        self.shard.load_state_dict(sd["shard"])
+        self.steps_since_reset = sd["steps_since_reset"]
+        self._clear_history()
+        self.last_obs = self.calc_Xk()
+
+
+_REGISTRY = {"mrs-v0": MRS}
+
+
+def make(env_id='mrs-v0', **kwargs):
+    """gym.make('mrs-v0', **kwargs) for installations without gym (mrsgym/__init__.py:13-16)."""
+    if env_id not in _REGISTRY:
+        raise KeyError("unknown environment id %r (registered: %s)" % (env_id, sorted(_REGISTRY)))
+    return _REGISTRY[env_id](**kwargs)
+
+
+def _register_with_gym():
+    if _gym is None:
+        return
+    try:
+        from gym.envs.registration import register  # type: ignore
+    except Exception:
+        try:
+            from gymnasium.envs.registration import register  # type: ignore
+        except Exception:
+            return
+    try:
+        register(id='mrs-v0', entry_point='mrsgym_amd:MRS')
+    except Exception:
+        pass
+
+
+_register_with_gym()

@@ -193,8 +193,10 @@ class SwarmShard:
     def _f32(x, device, shape):
         if x is None:
             return None
-        t = torch.as_tensor(x, device=device).to(torch.float32).reshape(shape).contiguous()
-        return t
+        t = torch.as_tensor(x, device=device).to(torch.float32)
+        if t.numel() * shape[0] == shape[0] * shape[1] * shape[2] and shape[0] > 1:
+            t = t.reshape(shape[1:]).unsqueeze(0).expand(shape)     # one (N,k) value shared by every env
+        return t.reshape(shape).contiguous()
 
     # ------------------------------------------------------------------ C-ABI calls
     def set_state(self, pos=None, ori=None, vel=None, angvel=None, env_mask=None):
@@ -206,13 +208,13 @@ class SwarmShard:
         kind = ORI_EULER
         if ori is not None:
             ori = torch.as_tensor(ori, device=dev).to(torch.float32)
-            tail = tuple(ori.shape[-2:])
-            if ori.shape[-1] == 3 and tail != (3, 3):
-                kind, ori = ORI_EULER, ori.reshape(E, N, 3).contiguous()
-            elif ori.shape[-1] == 4:
-                kind, ori = ORI_QUAT, ori.reshape(E, N, 4).contiguous()
-            else:
-                kind, ori = ORI_MATRIX, ori.reshape(E, N, 9).contiguous()
+            if E > 1 and ori.numel() in (3 * N, 4 * N, 9 * N) and ori.shape[0] == N:
+                ori = ori.unsqueeze(0).expand(E, *ori.shape)         # one (N,k) value shared by every env
+            per_agent = ori.numel() // (E * N)      # 3 euler | 4 quat | 9 matrix (Object.py:51-56)
+            if per_agent * E * N != ori.numel() or per_agent not in (3, 4, 9):
+                raise ValueError("ori has %d elements, expected (E,N,3|4|3x3)" % ori.numel())
+            kind = {3: ORI_EULER, 4: ORI_QUAT, 9: ORI_MATRIX}[per_agent]
+            ori = ori.reshape(E, N, per_agent).contiguous()
         mask = None if env_mask is None else torch.as_tensor(env_mask, device=dev).to(torch.uint8).contiguous()
         b = self._buffers()
         _check(self.L.mrs_set_state(self.h, C.byref(b), _ptr(pos), _ptr(ori), kind, _ptr(vel), _ptr(angvel), _ptr(mask),

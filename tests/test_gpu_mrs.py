@@ -1,0 +1,201 @@
+"""The drop-in Gym surface (mrsgym_amd.MRS / make('mrs-v0')) on the GPU, read like the reference's
+README / examples would exercise it, and checked against the reference's own MRS.step() outputs
+(tests/golden/F6, fake-bullet harness)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from util_scenarios import ActionStream, grid_spawn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def state_fn(quad):
+    return torch.cat([quad.get_pos(), quad.get_vel()])
+
+
+def state_fn_full(quad):
+    return torch.cat([quad.get_pos(), quad.get_ori(), quad.get_vel(), quad.get_angvel()])
+
+
+def test_readme_example_plumbing():
+    """README.md:14-33: N=3, set_target_vel, state_fn = cat(pos, vel) (BASELINE config 1)."""
+    import mrsgym_amd
+    N = 3
+    env = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, ACTION_TYPE='set_target_vel')
+    assert env._obs.fused and env._obs.fields == ("pos", "vel")
+    for _ in range(20):
+        actions = torch.tensor([0.5, 0.0, 0.0]).expand(N, -1)
+        X, reward, done, info = env.step(actions)
+    assert X.shape == (1, N, 6) and X.dtype == torch.float32           # (K+1, N, D), MRS.py:99
+    assert info["A"].shape == (1, N, N) and reward == 0.0 and done is False
+    assert torch.equal(info["A"][0].cpu(), torch.ones(N, N) - torch.eye(N))   # COMM_RANGE = inf, MRS.py:118-119
+    assert float(X[0, :, 3].mean()) > 0.0                               # moving along +x
+    env.wait(0.0)
+    env.close()
+
+
+def test_default_spawn_and_reset_semantics():
+    import mrsgym_amd
+    N = 12
+    env = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, K_HOPS=2, COMM_RANGE=2.5, SEED=3)
+    X = env.reset()
+    assert X.shape == (3, N, 6)
+    assert torch.equal(X[0], X[1]) and torch.equal(X[0], X[2])         # padded with copies (MRS.py:92-93)
+    p = X[0, :, :3].cpu().numpy()
+    assert (np.hypot(p[:, 0], p[:, 1]) <= 1 + 1e-6).all() and (p[:, 2] >= 1).all() and (p[:, 2] <= 3).all()
+    d = np.linalg.norm(p[:, None] - p[None], axis=-1) + np.eye(N) * 1e9
+    assert d.min() >= 0.6 - 1e-6
+    assert torch.all(X[0, :, 3:] == 0)
+    X2 = env.reset()
+    assert not torch.equal(X, X2)                                       # re-sampled
+    Xs, r, dn, info = env.step(torch.zeros(N, 3))
+    A = info["A"]
+    assert A.shape == (3, N, N) and float(A[1:].abs().sum()) == 0      # A history padded with zeros (MRS.py:107-108)
+    Xs2, _, _, info2 = env.step(torch.zeros(N, 3))
+    assert torch.equal(info2["A"][1], A[0]) and torch.equal(Xs2[1], Xs[0])
+    # explicit pos / vel override (README.md:82-95); set() keeps what is not given (MRS.py:196-205)
+    pos = torch.tensor(grid_spawn(1, N)[0][0])
+    X3 = env.reset(pos=pos, vel=torch.ones(N, 3))
+    np.testing.assert_array_equal(X3[0, :, :3].cpu().numpy(), pos.numpy())
+    assert torch.all(X3[0, :, 3:] == 1)
+    X4 = env.set(vel=torch.zeros(N, 3))
+    np.testing.assert_array_equal(X4[0, :, :3].cpu().numpy(), pos.numpy())
+    assert torch.all(X4[0, :, 3:] == 0) and env.steps_since_reset == 0
+    # N = 64 does not fit the default volume: the reference spins forever, we raise
+    with pytest.raises(RuntimeError):
+        mrsgym_amd.make('mrs-v0', N_AGENTS=64, state_fn=state_fn)
+
+
+def test_callbacks_and_quirks():
+    import mrsgym_amd
+    N = 5
+    seen = {}
+
+    def reward_fn(env, X, A, Xlast, action, steps_since_reset):
+        seen["reward"] = (X.shape, A.shape, Xlast is not X, steps_since_reset, env.get_pos().shape)
+        return -float(X[0, :, 2].mean())
+
+    def info_fn(**kw):
+        seen["info_xlast_is_x"] = kw["Xlast"] is kw["X"]               # MRS.py:264-266 quirk
+        return {"t": kw["steps_since_reset"]}
+
+    def update_fn(**kw):
+        seen["update"] = True
+
+    def start_fn(gymenv):
+        gymenv.set_data("target_vel", torch.randn(gymenv.N_AGENTS, 3, device=gymenv.device))
+
+    def generic_state_fn(quad):                                          # magent.py:35-37: not fusable
+        tv = quad.get_data("target_vel")[quad.get_idx(), :]
+        return torch.cat([tv - quad.get_vel()])
+
+    pos = torch.tensor(grid_spawn(1, N)[0][0])
+    env = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=generic_state_fn, reward_fn=reward_fn, info_fn=info_fn,
+                          update_fn=update_fn, start_fn=start_fn, MAX_TIMESTEPS=3, START_POS=pos, COMM_RANGE=1.5)
+    assert not env._obs.fused
+    X = env.reset()
+    assert X.shape == (1, N, 3)
+    np.testing.assert_allclose(X[0].cpu().numpy(), env.get_data("target_vel").cpu().numpy(), atol=1e-7)
+    dones = []
+    for t in range(4):
+        X, r, d, info = env.step(torch.zeros(N, 3))
+        dones.append(d)
+        assert info["t"] == t and isinstance(r, float)
+    assert dones == [False, False, False, True]                         # steps_since_reset >= MAX_TIMESTEPS before the increment
+    assert seen["reward"][0] == (1, N, 3) and seen["reward"][1] == (1, N, N) and seen["reward"][4] == (N, 3)
+    assert seen["info_xlast_is_x"] and seen["update"]
+    # step(None) skips the actions entirely (MRS.py:243-253); unknown ACTION_TYPE -> AttributeError
+    env.step(None)
+    with pytest.raises(AttributeError):
+        env.step(torch.zeros(N, 3), ACTION_TYPE="set_force")            # README.md:68 has no implementation
+    with pytest.raises(Exception, match="NaN"):
+        env.step(torch.full((N, 3), float("nan")))                      # MRS.py:247-248
+    # per-agent views
+    q = env.get_agents()[2]
+    assert q.get_idx() == 2 and q.get_pos().shape == (3,) and q.get_ori().shape == (3,) and q.get_ori(mat=True).shape == (3, 3)
+    np.testing.assert_allclose(q.get_pos().cpu().numpy(), env.get_env().get_pos()[2].cpu().numpy())
+    assert env.get_env().draw_links(None) is None and env.get_env().set_colour(q, [1, 0, 0]) is None
+
+
+F6 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F6_step_N*.npz")))
+
+
+@pytest.mark.parametrize("path", F6, ids=[os.path.basename(p)[8:-4] for p in F6])
+def test_reference_mrs_step_outputs(path):
+    """Drive our MRS with the reference run's inputs; X / A / reward / done must match the reference's
+    own step() outputs while the trajectory is still in its pre-chaotic window (first 40 steps)."""
+    import mrsgym_amd
+    d = np.load(path)
+    name = os.path.basename(path)[8:-4]
+    N, atype = int(name.split("_")[0][1:]), name.split("_", 1)[1]
+    D, K, cr = int(d["D"]), int(d["K_HOPS"]), float(d["COMM_RANGE"])
+    env = mrsgym_amd.make('mrs-v0', state_fn=state_fn_full if D == 12 else state_fn, N_AGENTS=N, K_HOPS=K, COMM_RANGE=cr,
+                          ACTION_TYPE=atype, HEADLESS=True, START_POS=torch.tensor(d["start"]))
+    X0 = env.reset(ori=torch.tensor(d["ori0"]))
+    np.testing.assert_allclose(X0.cpu().numpy(), d["X0"], rtol=0, atol=1e-6)
+    for t in range(40):
+        X, r, dn, info = env.step(torch.tensor(d["actions"][t]))
+        np.testing.assert_allclose(X.cpu().numpy(), d["X"][t], rtol=0, atol=2e-5, err_msg="%s t=%d" % (name, t))
+        mism = (info["A"].cpu().numpy().astype(np.uint8) != d["A"][t]).sum()
+        assert mism == 0, (name, t, mism)
+        assert r == d["reward"][t] and dn == bool(d["done"][t])
+
+
+def test_vectorised_envs_match_single_env_runs():
+    """N_ENVS = E adds a leading axis and nothing else: env e of the batch == a single-env run of env e."""
+    import mrsgym_amd
+    E, N, K = 3, 12, 1
+    pos, eul = grid_spawn(E, N, yaw_range=0.8)
+    acts = ActionStream("set_target_vel", E, N, pos, seed=4, coherent=True)
+    batch = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.5,
+                            START_POS=torch.tensor(pos))
+    batch.reset(ori=torch.tensor(eul))
+    singles = []
+    for e in range(E):
+        s = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.5, START_POS=torch.tensor(pos[e]))
+        s.reset(ori=torch.tensor(eul[e]))
+        singles.append(s)
+    for t in range(30):
+        a = torch.tensor(acts(t))
+        Xb, rb, db, ib = batch.step(a)
+        assert Xb.shape == (E, K + 1, N, 6) and ib["A"].shape == (E, K + 1, N, N)
+        for e, s in enumerate(singles):
+            Xs, _, _, is_ = s.step(a[e])
+            assert torch.equal(Xs, Xb[e]) and torch.equal(is_["A"], ib["A"][e])
+    # packed adjacency format carries the same bits
+    pk = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.5,
+                         START_POS=torch.tensor(pos), A_FORMAT="packed", RETURN_A=True)
+    pk.reset(ori=torch.tensor(eul))
+    acts = ActionStream("set_target_vel", E, N, pos, seed=4, coherent=True)
+    b2 = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.5, START_POS=torch.tensor(pos))
+    b2.reset(ori=torch.tensor(eul))
+    for t in range(5):
+        a = torch.tensor(acts(t))
+        _, _, _, ip = pk.step(a)
+        _, _, _, idn = b2.step(a)
+    bits = ip["A"][..., 0]                                              # (E,K+1,N) int64 rows, N <= 64
+    dense = ((bits.unsqueeze(-1) >> torch.arange(N, device=bits.device)) & 1).float()
+    assert torch.equal(dense, idn["A"])
+    # RETURN_A=False skips the adjacency (README.md:62 semantics; upstream ignores the flag)
+    na = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, START_POS=torch.tensor(pos[0]), RETURN_A=False)
+    _, _, _, info = na.step(torch.zeros(N, 3))
+    assert "A" not in info
+
+
+def test_checkpoint_roundtrip():
+    import mrsgym_amd
+    N = 6
+    pos = torch.tensor(grid_spawn(1, N)[0][0])
+    env = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, START_POS=pos)
+    for t in range(10):
+        env.step(torch.full((N, 3), 0.2))
+    sd = env.state_dict()
+    a = [env.step(torch.full((N, 3), -0.1))[0].clone() for _ in range(5)]
+    env.load_state_dict(sd)
+    b = [env.step(torch.full((N, 3), -0.1))[0].clone() for _ in range(5)]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

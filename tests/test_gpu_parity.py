@@ -14,13 +14,24 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _mk(E, N, atype, obs_fields=("pos", "vel"), seed=0, params=None):
+OPEN_LOOP = ("set_speeds", "set_control", "set_target_accel", "set_target_ori")
+
+
+def _mk(E, N, atype, obs_fields=("pos", "vel"), seed=0, no_ground=None):
+    """no_ground: remove the ground plane (open-loop ACTION_TYPEs eventually fall; ground impacts are
+    chaotic and are covered by the touchdown test with its own stated tolerance)."""
     import mrsgym_amd
-    pos, eul = grid_spawn(E, N, seed=seed)
+    pos, eul = grid_spawn(E, N, seed=seed, yaw_range=0.8)   # |yaw| <= 0.8: see util_scenarios.ActionStream
     sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", obs_fields=obs_fields, want_rpm=True)
     z = np.zeros((E, N, 3), np.float32)
     sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
     sw = oracle.OracleSwarm(E, N, nthreads=8)
+    if no_ground is None:
+        no_ground = atype in OPEN_LOOP
+    if no_ground:
+        p = mrsgym_amd.default_params(); p.enable_contact = 0; p.ground_z = -1e9
+        sh.set_params(p)
+        sw.p.enable_contact = 0; sw.p.ground_z = -1e9
     sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z.astype(np.float64), angvel=z.astype(np.float64))
     return sh, sw, pos
 
@@ -82,7 +93,7 @@ def test_set_state_and_observe_match_oracle():
 @pytest.mark.parametrize("E,N", [(5, 3), (3, 12), (6, 64)])
 def test_step_parity_200_steps(atype, E, N):
     sh, sw, pos0 = _mk(E, N, atype)
-    acts = ActionStream(atype, E, N, pos0, seed=7) if atype else None
+    acts = ActionStream(atype, E, N, pos0, seed=7, coherent=True) if atype else None
     obs = torch.zeros(E, N, sh.D, device="cuda:0")
     adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
     dense = torch.zeros(E, N, N, device="cuda:0")
@@ -91,7 +102,7 @@ def test_step_parity_200_steps(atype, E, N):
         sh.step(None if a is None else torch.from_numpy(a).cuda(), atype, obs_out=obs, adj_out=adj, comm_range=2.5)
         sw.step(a, atype)
         if t % 50 == 49 or t < 3:
-            _compare(sh, sw, 1e-6, "%s E%d N%d t=%d" % (atype, E, N, t))
+            _compare(sh, sw, 1e-9 if t < 3 else 1e-6, "%s E%d N%d t=%d" % (atype, E, N, t))
             if atype:
                 np.testing.assert_allclose(sh.view(sh.rpm).cpu().numpy(), sw.speeds, rtol=2e-6, atol=1e-2)
             # adjacency from the GPU's own positions must equal the oracle's calc_A on those positions
@@ -110,12 +121,7 @@ def test_north_star_tolerance_1000_steps(atype):
     set_speeds case runs with contact disabled so that tumbling ground impacts do not enter)."""
     E, N = 4, 64
     sh, sw, pos0 = _mk(E, N, atype)
-    if atype == "set_speeds":
-        import mrsgym_amd
-        p = mrsgym_amd.default_params(); p.enable_contact = 0; p.ground_z = -1e9
-        sh.set_params(p)
-        sw.p.enable_contact = 0; sw.p.ground_z = -1e9
-    acts = ActionStream(atype, E, N, pos0, seed=11)
+    acts = ActionStream(atype, E, N, pos0, seed=11, coherent=True)
     worst = {}
     for t in range(1000):
         a = acts(t)
@@ -225,7 +231,7 @@ def test_large_n_and_ragged_blocks():
             a = acts(t)
             sh.step(torch.from_numpy(a).cuda(), atype, adj_out=adj, comm_range=5.0)
             sw.step(a, atype)
-        _compare(sh, sw, 1e-7, "E%d N%d %s" % (E, N, atype))
+        _compare(sh, sw, 1e-6, "E%d N%d %s" % (E, N, atype))
         sh.adjacency_expand(adj, dense)
         p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
         want = np.stack([oracle.adjacency(p32[e], 5.0) for e in range(E)])

@@ -1,0 +1,94 @@
+"""Host-side logic of the product package on CPU tensors (no GPU, no compute calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mrsgym_amd.facade import StateFnCompiler
+from mrsgym_amd.history import HistoryRing
+from mrsgym_amd.util import CombinedDistribution, SphereTransform, randrange, totensor
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("K", [0, 1, 3])
+@pytest.mark.parametrize("slots", [0, 2, 5])
+def test_history_ring_reproduces_reference_deques(K, slots):
+    """tests/golden/F4: calc_Xk pads with copies of X, calc_Ak with zeros, both newest-first (MRS.py:87-114)."""
+    d = np.load(os.path.join(G, "F4_history.npz"))
+    seqX, Xk, Ak = d["K%d_seqX" % K], d["K%d_Xk" % K], d["K%d_Ak" % K]
+    T, N, D = seqX.shape
+    xr = HistoryRing(K, (1, N, D), torch.float32, "cpu", slots=slots, pad="copy")
+    ar = HistoryRing(K, (1, N, N), torch.float32, "cpu", slots=slots, pad="zero")
+    seqP = d["K%d_seqP" % K]
+    for rep in range(2):                      # second pass = after reset(): deques cleared
+        xr.clear(); ar.clear()
+        for t in range(T):
+            xr.buf[xr.next_slot()][0] = torch.from_numpy(seqX[t])
+            xr.committed()
+            np.testing.assert_array_equal(xr.window()[:, 0].numpy(), Xk[t])
+            if t >= 1:
+                p = torch.from_numpy(seqP[t])
+                A = ((p[:, None] - p[None]).norm(dim=2) <= 2.0).float()
+                A.fill_diagonal_(0)
+                ar.buf[ar.next_slot()][0] = A
+                ar.committed()
+                np.testing.assert_array_equal(ar.window()[:, 0].numpy(), Ak[t - 1])
+
+
+def test_history_ring_long_run_wraps():
+    K, L = 3, 9
+    r = HistoryRing(K, (2,), torch.float32, "cpu", slots=L, pad="copy")
+    for t in range(100):
+        r.buf[r.next_slot()][:] = t
+        r.committed()
+        want = [max(t - k, 0) for k in range(K + 1)]
+        assert r.window()[:, 0].tolist() == want
+        assert r.window().data_ptr() == r.buf[r.head].data_ptr()       # a view, never a copy
+
+
+class _FakeShard:
+    E, N = 1, 3
+
+
+def _recognise(fn):
+    c = StateFnCompiler.__new__(StateFnCompiler)
+    return c._recognise(fn)
+
+
+def test_state_fn_recogniser():
+    assert _recognise(lambda q: torch.cat([q.get_pos(), q.get_vel()])) == ("pos", "vel")           # README.md:28-29
+    assert _recognise(lambda q: torch.cat([q.get_pos(), q.get_ori(), q.get_vel(), q.get_angvel()])) == \
+        ("pos", "ori", "vel", "angvel")
+    assert _recognise(lambda q: q.get_vel()) == ("vel",)
+    assert _recognise(lambda q: torch.cat([q.get_vel(), q.get_pos()])) == ("vel", "pos")
+    # not plain concatenations -> generic (vmap) path
+    assert _recognise(lambda q: torch.cat([q.get_pos() * 2, q.get_vel()])) is None
+    assert _recognise(lambda q: torch.cat([q.get_data("target")[q.get_idx()] - q.get_vel()])) is None  # magent.py:35-37
+    assert _recognise(lambda q: torch.zeros(3)) is None
+    assert _recognise(lambda q: torch.cat([q.get_pos(), q.get_ori(mat=True).flatten()])) is None
+
+
+def test_default_spawn_distribution_properties():
+    """Properties of MRS.default_spawn_dist (MRS.py:69-78) as captured in tests/golden/F5."""
+    from torch.distributions import Normal, TransformedDistribution, Uniform
+    d = np.load(os.path.join(G, "F5_spawn.npz"))
+    for N in (3, 12, 32):
+        ref = d["N%d" % N]
+        assert (np.hypot(ref[..., 0], ref[..., 1]) <= 1 + 1e-6).all() and (ref[..., 2] >= 1).all() and (ref[..., 2] <= 3).all()
+        dist = np.linalg.norm(ref[:, :, None] - ref[:, None], axis=-1) + np.eye(N) * 1e9
+        assert dist.min() >= 0.6 - 1e-6
+        z = Uniform(low=torch.ones(N, 1), high=3 * torch.ones(N, 1))
+        xy = TransformedDistribution(Normal(torch.zeros(N, 2), 1.0), [SphereTransform(radius=1.0, within=True)])
+        ours = CombinedDistribution([xy, z], mixer='cat', dim=1)
+        s = torch.stack([ours.sample() for _ in range(200)])
+        assert s.shape == (200, N, 3)
+        r = s[..., :2].norm(dim=-1)
+        assert float(r.max()) <= 1 + 1e-6 and 0.5 < float((r > 1 - 1e-6).float().mean()) < 0.72   # P(|N(0,I)|>1) = e^-0.5 = 0.607
+        assert float(s[..., 2].min()) >= 1 and float(s[..., 2].max()) <= 3
+    ori = d["ori_N16"]
+    assert np.all(ori[..., :2] == 0) and np.abs(ori[..., 2]).max() <= np.pi / 2
+    x = randrange(torch.tensor([0., 0., -1.]), torch.tensor([0., 0., 1.]))
+    assert x.shape == (3,) and x[0] == 0 and abs(float(x[2])) <= 1
+    assert totensor([1, 2]).tolist() == [1, 2]
