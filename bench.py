@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the MRS.step() hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by torch.distributed.run, one rank per GPU; reads RANK/LOCAL_RANK/WORLD_SIZE)
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): N_AGENTS=64 x 4096 envs per GPU,
+ACTION_TYPE=set_target_vel (cascaded PID), RETURN_A=True, COMM_RANGE=5.0, K_HOPS=3, state_fn =
+cat(pos, vel); synthetic swarm of SURVEY.md 8d (grid spawn, per-agent U[-1,1]^3 m/s targets held 50
+steps, pre-generated on the device).  One "step" = one env.step(actions) of the product API over the
+whole batch: fused controller + rotor/aero forces + downwash + 6-DoF integration + ground contact +
+newest observation slice + bit-packed newest adjacency rows, written into the K_HOPS history ring.
+Weak scaling: every GPU owns 4096 envs; with N>1 the newest observation slice is all-gathered over
+RCCL each step (side stream, overlapped).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM (algorithmic bytes,
+SURVEY.md 8d: 268 B per agent-step at this config); `cpu_baseline` times the CPU oracle (a C port of
+the reference's algorithm, OpenMP over envs) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mrs-gym_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+N_AGENTS, ENVS_PER_GPU, K_HOPS, COMM_RANGE, ATYPE = 64, 4096, 3, 5.0, "set_target_vel"
+# state r+w 104, action 12, PID state (set_target_vel, 15 words r+w) 120, obs slice 24, packed adjacency row 8
+ALGO_BYTES_PER_AGENT_STEP = 104 + 12 + 120 + 24 + 8
+HBM_PEAK_GBS = 8000.0
+
+
+def state_fn(quad):  # README.md:28-29
+    return torch.cat([quad.get_pos(), quad.get_vel()])
+
+
+def cpu_baseline(seconds=15.0):
+    """The CPU oracle (kind "port") on E=256 envs of the same workload, all host cores."""
+    import oracle
+    from util_scenarios import ActionStream, grid_spawn
+    cores = os.cpu_count() or 1
+    E = 256
+    pos, eul = grid_spawn(E, N_AGENTS)
+    z = np.zeros((E, N_AGENTS, 3))
+    sw = oracle.OracleSwarm(E, N_AGENTS, nthreads=cores)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z, angvel=z)
+    acts = ActionStream(ATYPE, E, N_AGENTS, pos, seed=1)
+    a = acts(0)
+    sw.step_full(a, ATYPE, COMM_RANGE)          # thread-pool warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        if n % 50 == 0:
+            a = acts(n)
+        sw.step_full(a, ATYPE, COMM_RANGE)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or n >= 2000:
+            break
+    return {"value": E * N_AGENTS * n / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d agents x %d steps of the same workload (C oracle, OpenMP over envs, %.1f s)" % (E, N_AGENTS, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--dense-a", action="store_true", help="materialise the float32 (E,K+1,N,N) adjacency the reference returns")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import mrsgym_amd
+    from mrsgym_amd import dist as mdist
+    from util_scenarios import ActionStream, grid_spawn
+    import torch.distributed as dist
+
+    rank, world, local = mdist.init_from_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    E, N = args.envs_per_gpu, N_AGENTS
+    base = rank * E
+    pos, eul = grid_spawn(E, N, env_base=base)
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
+                          RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos),
+                          A_FORMAT="dense" if args.dense_a else "packed", ENV_INDEX_BASE=base, DEVICE=str(dev),
+                          CHECK_NAN="lazy")
+    env.reset(ori=torch.from_numpy(eul))
+    assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
+    acts = ActionStream(ATYPE, E, N, pos, seed=1000 + rank)
+    total = args.warmup + args.steps
+    table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range(total // 50 + 1)]
+    gather = mdist.ObsAllGather(E, N, 6, dev) if world > 1 else None
+
+    def one_step(t):
+        X, r, d, info = env.step(table[t // 50])
+        if gather is not None:
+            gather.gather(env._Xring.newest())
+        return X, info
+
+    for t in range(args.warmup):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    # HIP events bracket every step-kernel launch on the stream it is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    shard_step = env.shard.step
+
+    def timed_step(*a, **k):
+        e0, e1 = ev[timed_step.i]
+        e0.record()
+        shard_step(*a, **k)
+        e1.record()
+        timed_step.i += 1
+    timed_step.i = 0
+    env.shard.step = timed_step
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        one_step(t)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    env.shard.step = shard_step
+    env.check_errors()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    agent_steps = float(E) * N * args.steps * world
+    value = agent_steps / elapsed
+    algo_bytes_launch = ALGO_BYTES_PER_AGENT_STEP * E * N
+    achieved = algo_bytes_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes (see profiles/README.md)
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("k_step_set_target_vel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "agent-steps/sec (whole node) at N_AGENTS=64 x4096 envs", "value": value, "unit": "agent-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "N_AGENTS=64 x %d envs/GPU, ACTION_TYPE=set_target_vel (PID), RETURN_A=True COMM_RANGE=5.0, "
+                               "K_HOPS=3, state_fn=cat(pos,vel), A %s" % (E, "dense fp32" if args.dense_a else "bit-packed"),
+                   "n_agents": N, "n_envs_per_gpu": E, "k_hops": K_HOPS, "comm_range": COMM_RANGE,
+                   "parallelism": "env-sharded x%d, obs all-gather" % world if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": algo_bytes_launch},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Multi-GPU: env instances shard embarrassingly (no cross-env term anywhere: downwash, adjacency
+and contact are intra-env -- Quadcopter.py:101, MRS.py:120), one process per GPU, contiguous blocks of
+E/G envs by GLOBAL env index.  Nothing is exchanged inside step(); the only collective is an
+all-gather of the newest observation slice (E_local, N, D) float32 so that every rank can see the
+joint observation.  The reference has no distributed code at all.
+
+The gather runs on a side stream and is double-buffered: step t+1's kernel overlaps gather t.
+Backend: torch.distributed ("nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_envs_total, rank, world):
+    """Contiguous env block of `rank`: [lo, hi) in global env indices (remainder to the low ranks)."""
+    base, rem = divmod(int(n_envs_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class ObsAllGather:
+    """all-gather of (E_local, N, D) slices into (world*E_local, N, D), overlapped with compute."""
+
+    def __init__(self, e_local, n_agents, d, device, group=None, buffers=2):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = torch.device(device)
+        self.out = [torch.empty(self.world * e_local, n_agents, d, dtype=torch.float32, device=self.device)
+                    for _ in range(buffers)]
+        self.k = 0
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.done = [None] * buffers
+
+    def gather(self, newest):
+        """Start gathering `newest` (contiguous (E_local,N,D)); returns the output buffer, complete after wait()."""
+        k = self.k
+        self.k = (k + 1) % len(self.out)
+        out = self.out[k]
+        if self.world == 1:
+            out.copy_(newest)
+            return out
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))      # the step kernel that wrote `newest`
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                dist.all_gather_into_tensor(out, newest, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.done[k] = ev
+        else:
+            parts = list(out.chunk(self.world, dim=0))
+            dist.all_gather(parts, newest.contiguous(), group=self.group)
+        return out
+
+    def wait(self):
+        """Make the compute stream wait for every gather issued so far."""
+        if self.cuda:
+            for ev in self.done:
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+
+
+def gather_global_state(local, group=None):
+    """Concatenate per-rank (E_local, ...) tensors in rank order (tests: 1-GPU vs sharded bitwise equality)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return torch.cat(parts, 0)

@@ -76,6 +76,7 @@ class MRS(_EnvBase):
         self.RESET_CONTROLLERS = False  # reference: PID integrators survive reset() (QuadControl objects persist)
         self.CHECK_NAN = None         # "sync" | "lazy" | "off"; None = sync for N_ENVS==1 else lazy
         self.HISTORY_SLOTS = 0        # ring length; 0 = 8*(K_HOPS+1)
+        self.COPY_OUTPUTS = None      # None = clone returned stacks iff N_ENVS == 1 (reference returns fresh tensors)
         # BulletSim constants (BulletSim.py:11-15); DT/GRAVITY reach the world only, never the controller
         self.REAL_TIME = False
         self.GRAVITY = 9.81
@@ -138,7 +139,12 @@ class MRS(_EnvBase):
 
     def _squeeze(self, t):
         """(E, ...) -> (...) when N_ENVS == 1 so that shapes equal the reference's."""
-        return t[0] if self.N_ENVS == 1 else t
+        if self.N_ENVS == 1:
+            t = t[0]
+        copy = self.COPY_OUTPUTS if self.COPY_OUTPUTS is not None else (self.N_ENVS == 1)
+        # the reference returns fresh tensors every step; views into the history ring are overwritten
+        # HISTORY_SLOTS steps later (or at the next reset), which is what a vectorised loop wants
+        return t.clone() if copy else t
 
     def _alloc_history(self):
         E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W

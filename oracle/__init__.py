@@ -99,6 +99,8 @@ def lib():
         _lib.orc_adjacency.argtypes = [C.c_int, fp, C.c_double, fp]
         _lib.orc_step.argtypes = [PP, C.c_int, C.c_int, dp, dp, dp, dp, C.c_void_p, fp, C.c_int, C.c_int, dp, dp, C.c_int]
         _lib.orc_integrate.argtypes = [PP, dp, dp, dp, dp, dp, dp]
+        _lib.orc_step_full.argtypes = [PP, C.c_int, C.c_int, dp, dp, dp, dp, C.c_void_p, fp, C.c_int, C.c_int,
+                                       C.c_double, fp, fp, C.c_int]
     return _lib
 
 
@@ -266,6 +268,19 @@ class OracleSwarm:
             a_ptr = _f(a)
         lib().orc_step(C.byref(self.p), self.E, self.N, _d(self.pos), _d(self.quat), _d(self.vel), _d(self.angvel),
                        self.pid.ctypes.data, a_ptr, at, adim, _d(self.speeds), _d(self.wrench), int(self.nthreads))
+
+    def step_full(self, actions, action_type, comm_range, want_A=True):
+        """CPU baseline: step + newest cat(pos, vel) slice + newest dense adjacency, env-parallel."""
+        at = ACT[action_type]
+        adim = ADIM[at]
+        a = f32(actions).reshape(self.E, self.N, adim)
+        if not hasattr(self, "_obs"):
+            self._obs = np.zeros((self.E, self.N, 6), np.float32)
+            self._A = np.zeros((self.E, self.N, self.N), np.float32)
+        lib().orc_step_full(C.byref(self.p), self.E, self.N, _d(self.pos), _d(self.quat), _d(self.vel), _d(self.angvel),
+                            self.pid.ctypes.data, _f(a), at, adim, float(comm_range), _f(self._obs),
+                            _f(self._A) if want_A else None, int(self.nthreads))
+        return self._obs, self._A
 
     def observe(self):
         """float32 read-back of every agent: dict of (E,N,3) arrays + (E,N,3,3) mat."""

@@ -749,3 +749,31 @@ void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, doubl
     }
     (void)nthreads;
 }
+
+/* The whole per-step hot path of MRS.step for the CPU baseline: step + newest observation slice
+ * (state_fn = cat(pos, vel), README.md:28-29) + newest adjacency (MRS.calc_A), env-parallel. */
+void orc_step_full(const OrcParams *p, int E, int N, double *pos, double *quat, double *vel, double *angvel,
+                   OrcPid *pid, const float *actions, int action_type, int adim, double comm_range,
+                   float *obs /* [E][N][6] */, float *A /* [E][N][N] or NULL */, int nthreads)
+{
+    double d[7];
+    orc_derived(p, d);
+    const double hclip = d[6];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        size_t o = (size_t)e * N;
+        step_env(p, N, pos + 3 * o, quat + 4 * o, vel + 3 * o, angvel + 3 * o, pid + o,
+                 actions ? actions + o * adim : 0, action_type, adim, 0, 0, hclip);
+        float p32[N][3];
+        for (int i = 0; i < N; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                p32[i][k] = (float)pos[3 * (o + i) + k];
+                obs[6 * (o + i) + k] = p32[i][k];
+                obs[6 * (o + i) + 3 + k] = (float)vel[3 * (o + i) + k];
+            }
+        }
+        if (A) orc_adjacency(N, &p32[0][0], comm_range, A + o * N);
+    }
+}

@@ -115,6 +115,11 @@ void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, doubl
               OrcPid *pid, const float *actions, int action_type, int adim, double *speeds_out, double *wrench_out,
               int nthreads);
 
+/* CPU baseline of the whole per-step hot path (step + cat(pos,vel) slice + adjacency), env-parallel. */
+void orc_step_full(const OrcParams *p, int E, int N, double *pos, double *quat, double *vel, double *angvel,
+                   OrcPid *pid, const float *actions, int action_type, int adim, double comm_range,
+                   float *obs, float *A, int nthreads);
+
 /* Pieces of orc_step, exposed so the reference's own Python can be driven on top of
  * them by tools/gen_golden.py (fake-bullet harness) and for unit tests. */
 void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3],
