@@ -45,8 +45,12 @@ def cpu_baseline(seconds=15.0):
     """The CPU oracle (kind "port") on E=256 envs of the same workload, all host cores."""
     import oracle
     from util_scenarios import ActionStream, grid_spawn
-    cores = os.cpu_count() or 1
-    E = 256
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MRS_CPU_BASELINE_THREADS", "16"))))   # a 1-GPU box's CPU share
+    E = 32 * cores
     pos, eul = grid_spawn(E, N_AGENTS)
     z = np.zeros((E, N_AGENTS, 3))
     sw = oracle.OracleSwarm(E, N_AGENTS, nthreads=cores)
