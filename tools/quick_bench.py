@@ -5,7 +5,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tes
 import numpy as np, torch, mrsgym_amd
 from util_scenarios import ActionStream, grid_spawn
 E = int(os.environ.get("E", 4096)); N = int(os.environ.get("N", 64)); K = int(os.environ.get("K", 300))
+ONLY = os.environ.get("ONLY")
 for atype, cr in [("set_target_vel", 5.0), ("set_speeds", float("nan")), ("set_target_pos", 5.0), ("set_control", 5.0), (None, 5.0)]:
+    if ONLY and str(atype) != ONLY:
+        continue
     pos, eul = grid_spawn(E, N)
     z = np.zeros((E, N, 3), np.float32)
     sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
