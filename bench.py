@@ -121,7 +121,7 @@ def main():
         torch.cuda.synchronize()
     # HIP events bracket every step-kernel launch on the stream it is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    shard_step = env.shard.step
+    shard_step = env.shard.step_ptr
 
     def timed_step(*a, **k):
         e0, e1 = ev[timed_step.i]
@@ -130,7 +130,7 @@ def main():
         e1.record()
         timed_step.i += 1
     timed_step.i = 0
-    env.shard.step = timed_step
+    env.shard.step_ptr = timed_step
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
         one_step(t)
@@ -141,7 +141,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    env.shard.step = shard_step
+    env.shard.step_ptr = shard_step
     env.check_errors()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if world > 1:

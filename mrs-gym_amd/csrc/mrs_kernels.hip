@@ -134,6 +134,26 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
 
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
+        // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane.
+        // Runs FIRST, while only the 13 state words are live: the controller's registers (PID memory,
+        // rotation matrices) do not have to survive the 64-iteration loop, which is what keeps the
+        // kernel at 4 resident waves per SIMD.
+        double downwash_acc = 0;
+        if (ACT != MRS_ACT_NONE) {
+            const float4 *tile_env = lds_tile + el * A.N;
+            const DownwashConst dc = downwash_const(A.P);
+            const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
+#pragma unroll 4
+            for (int j = 0; j < A.N; ++j) {
+                const float4 pj = tile_env[j];
+#if MRS_EXACT_F32
+                const float f = downwash_pair(f32sub(pj.x, mx), f32sub(pj.y, my), f32sub(pj.z, mz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
+#else
+                const float f = downwash_pair_fast(pj.x - mx, pj.y - my, pj.z - mz, dc);
+#endif
+                downwash_acc += (double)f;
+            }
+        }
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
             Observed ob;
@@ -141,15 +161,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             double rpm[4];
             constexpr bool NEEDS_PID = (ACT >= MRS_ACT_TARGET_ACCEL);
             if (NEEDS_PID) {
-                Pid s;
-                const double *g = A.b.pid64 + a;
-                const float *h = A.b.pid32 + a;
-                s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T];
-                s.dvx = g[3 * T]; s.dvy = g[4 * T]; s.dvz = g[5 * T];
-                s.ivx = g[6 * T]; s.ivy = g[7 * T]; s.ivz = g[8 * T];
+                // controller memory: only the planes this ACTION_TYPE touches are moved (set_target_vel 15
+                // words, set_target_pos 6, set_target_accel / set_target_ori 3)
+                Pid s = {};
+                const float *g = A.b.pid + a;
+                if (ACT == MRS_ACT_TARGET_POS) { s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T]; }
+                if (ACT == MRS_ACT_TARGET_VEL) {
+                    s.dvx = g[3 * T]; s.dvy = g[4 * T]; s.dvz = g[5 * T];
+                    s.ivx = g[6 * T]; s.ivy = g[7 * T]; s.ivz = g[8 * T];
+                    s.lvx = g[12 * T]; s.lvy = g[13 * T]; s.lvz = g[14 * T];
+                    s.ltx = g[15 * T]; s.lty = g[16 * T]; s.ltz = g[17 * T];
+                }
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
-                s.lvx = h[0]; s.lvy = h[T]; s.lvz = h[2 * T];
-                s.ltx = h[3 * T]; s.lty = h[4 * T]; s.ltz = h[5 * T];
                 const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
@@ -161,16 +184,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
                     else ta = v3((double)act[0], (double)act[1], (double)act[2]);
                     accel_control(P, A.rc, s, ta, R, ob, rpm);
                 }
-                double *go = A.b.pid64 + a;
-                float *ho = A.b.pid32 + a;
-                if (ACT == MRS_ACT_TARGET_POS) { go[0] = s.ipx; go[T] = s.ipy; go[2 * T] = s.ipz; }
+                float *go = A.b.pid + a;
+                if (ACT == MRS_ACT_TARGET_POS) { go[0] = (float)s.ipx; go[T] = (float)s.ipy; go[2 * T] = (float)s.ipz; }
                 if (ACT == MRS_ACT_TARGET_VEL) {
-                    go[3 * T] = s.dvx; go[4 * T] = s.dvy; go[5 * T] = s.dvz;
-                    go[6 * T] = s.ivx; go[7 * T] = s.ivy; go[8 * T] = s.ivz;
-                    ho[0] = s.lvx; ho[T] = s.lvy; ho[2 * T] = s.lvz;
-                    ho[3 * T] = s.ltx; ho[4 * T] = s.lty; ho[5 * T] = s.ltz;
+                    go[3 * T] = (float)s.dvx; go[4 * T] = (float)s.dvy; go[5 * T] = (float)s.dvz;
+                    go[6 * T] = (float)s.ivx; go[7 * T] = (float)s.ivy; go[8 * T] = (float)s.ivz;
+                    go[12 * T] = s.lvx; go[13 * T] = s.lvy; go[14 * T] = s.lvz;
+                    go[15 * T] = s.ltx; go[16 * T] = s.lty; go[17 * T] = s.ltz;
                 }
-                go[9 * T] = s.iox; go[10 * T] = s.ioy; go[11 * T] = s.ioz;
+                go[9 * T] = (float)s.iox; go[10 * T] = (float)s.ioy; go[11 * T] = (float)s.ioz;
             } else if (ACT == MRS_ACT_SET_CONTROL) {
                 set_control(P, act[0], act[1], act[2], act[3], rpm);
             } else {
@@ -237,23 +259,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
                 fb.y += (double)ob.r10 * t0 + (double)ob.r11 * t1 + (double)ob.r12 * t2;
                 fb.z += (double)ob.r20 * t0 + (double)ob.r21 * t1 + (double)ob.r22 * t2;
             }
-            // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane
-            {
-                const float4 *tile_env = lds_tile + el * A.N;
-                const DownwashConst dc = downwash_const(P);
-                double acc = 0;
-#pragma unroll 4
-                for (int j = 0; j < A.N; ++j) {
-                    const float4 pj = tile_env[j];
-#if MRS_EXACT_F32
-                    const float f = downwash_pair(f32sub(pj.x, ob.px), f32sub(pj.y, ob.py), f32sub(pj.z, ob.pz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
-#else
-                    const float f = downwash_pair_fast(pj.x - ob.px, pj.y - ob.py, pj.z - ob.pz, dc);
-#endif
-                    acc += (double)f;
-                }
-                fb.z += acc;
-            }
+            fb.z += downwash_acc;
         }
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
         if (needs_contact(A.P, p[2])) {
@@ -372,8 +378,8 @@ __global__ void k_pid_reset(MrsBuffers b, const uint8_t *mask, int N, size_t T)
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= T) return;
     if (mask && !mask[a / N]) return;
-    for (int k = 0; k < 12; ++k) b.pid64[k * T + a] = 0.0;
-    for (int k = 0; k < 6; ++k) b.pid32[k * T + a] = __builtin_nanf("");
+    for (int k = 0; k < 12; ++k) b.pid[k * T + a] = 0.0f;
+    for (int k = 12; k < 18; ++k) b.pid[k * T + a] = __builtin_nanf("");
 }
 
 // ------------------------------------------------------------------------------------------ spawn
@@ -673,7 +679,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     if (action_type < MRS_ACT_NONE || action_type > MRS_ACT_TARGET_ORI)
         return fail(MRS_E_ACTION_TYPE, "mrs_step: unknown ACTION_TYPE (the reference raises AttributeError, Environment.py:92)");
     if (action_type != MRS_ACT_NONE && !actions) return fail(MRS_E_ARG, "mrs_step: actions is NULL");
-    if (action_type >= MRS_ACT_TARGET_ACCEL && (!b->pid64 || !b->pid32)) return fail(MRS_E_ARG, "mrs_step: PID buffers missing");
+    if (action_type >= MRS_ACT_TARGET_ACCEL && !b->pid) return fail(MRS_E_ARG, "mrs_step: PID buffer missing");
     StepArgs A;
     int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
     if (rc) return rc;
@@ -783,7 +789,7 @@ extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double
 
 extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream)
 {
-    if (!h || !b || !b->pid64 || !b->pid32) return fail(MRS_E_ARG, "mrs_pid_reset: NULL handle/buffers");
+    if (!h || !b || !b->pid) return fail(MRS_E_ARG, "mrs_pid_reset: NULL handle/buffers");
     const size_t T = (size_t)h->E * h->N;
     const int block = 256;
     hipLaunchKernelGGL(k_pid_reset, dim3((unsigned)((T + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, *b, env_mask, h->N, T);

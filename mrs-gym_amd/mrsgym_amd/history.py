@@ -8,16 +8,24 @@ when it gets there the K surviving slices are moved to the far end (once every L
 
 Padding rules pinned by tests/golden/F4: X is padded with copies of the first slice (MRS.py:92-93),
 A with zeros (MRS.py:107-108).
+
+Everything per-step is plain Python integer work: slot pointers are base + slot*stride and the
+window views are built once per head position and cached (a torch view op costs microseconds, the
+step kernel tens of them).
 """
 import torch
 
 
 class HistoryRing:
-    def __init__(self, k_hops, slice_shape, dtype, device, slots=0, pad="copy"):
+    def __init__(self, k_hops, slice_shape, dtype, device, slots=0, pad="copy", view_fn=None):
         self.K = int(k_hops)
         self.L = max(int(slots) if slots else 8 * (self.K + 1), 2 * (self.K + 1))
         self.pad = pad
         self.buf = torch.zeros((self.L,) + tuple(slice_shape), dtype=dtype, device=device)
+        self._base = self.buf.data_ptr()
+        self._stride = self.buf[0].numel() * self.buf.element_size()
+        self._view_fn = view_fn or (lambda w: w)
+        self._views = {}
         self.clear()
 
     def clear(self):
@@ -39,6 +47,9 @@ class HistoryRing:
                 self.head -= 1
         return self.head
 
+    def ptr(self, slot):
+        return self._base + slot * self._stride
+
     def committed(self):
         """Call after the newest slice has been written (possibly asynchronously, same stream)."""
         if self.count == 0 and self.K > 0:
@@ -46,7 +57,8 @@ class HistoryRing:
                 self.buf[self.head + 1:self.head + 1 + self.K] = self.buf[self.head].unsqueeze(0)
             else:
                 self.buf[self.head + 1:self.head + 1 + self.K].zero_()
-        self.count = min(self.count + 1, self.K + 1)
+        if self.count <= self.K:
+            self.count += 1
 
     def newest(self):
         return self.buf[self.head]
@@ -54,3 +66,10 @@ class HistoryRing:
     def window(self):
         """(K+1, ...) newest first, a view."""
         return self.buf[self.head:self.head + self.K + 1]
+
+    def view(self):
+        """view_fn(window()), cached per head position."""
+        v = self._views.get(self.head)
+        if v is None:
+            v = self._views[self.head] = self._view_fn(self.window())
+        return v

@@ -139,25 +139,32 @@ class MRS(_EnvBase):
 
     def _squeeze(self, t):
         """(E, ...) -> (...) when N_ENVS == 1 so that shapes equal the reference's."""
-        if self.N_ENVS == 1:
-            t = t[0]
-        copy = self.COPY_OUTPUTS if self.COPY_OUTPUTS is not None else (self.N_ENVS == 1)
+        return t[0] if self.N_ENVS == 1 else t
+
+    def _stack_view(self, w):
+        """ring window (K+1, E, ...) -> the reference's stack layout (E, K+1, ...) / (K+1, ...) for one env."""
+        return self._squeeze(w.permute(1, 0, 2, 3))
+
+    def _out(self, t):
         # the reference returns fresh tensors every step; views into the history ring are overwritten
         # HISTORY_SLOTS steps later (or at the next reset), which is what a vectorised loop wants
+        copy = self.COPY_OUTPUTS if self.COPY_OUTPUTS is not None else (self.N_ENVS == 1)
         return t.clone() if copy else t
 
     def _alloc_history(self):
         E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
         self._Xring = None            # allocated once D is known (StateFnCompiler)
-        self._Apacked = HistoryRing(self.K_HOPS, (E, N, W), torch.int64, self.device, self.HISTORY_SLOTS, pad="zero")
+        self._Apacked = HistoryRing(self.K_HOPS, (E, N, W), torch.int64, self.device, self.HISTORY_SLOTS, pad="zero",
+                                    view_fn=self._stack_view)
         self._Adense = None
         if self.A_FORMAT == "dense":
-            self._Adense = HistoryRing(self.K_HOPS, (E, N, N), torch.float32, self.device, self.HISTORY_SLOTS, pad="zero")
+            self._Adense = HistoryRing(self.K_HOPS, (E, N, N), torch.float32, self.device, self.HISTORY_SLOTS, pad="zero",
+                                       view_fn=self._stack_view)
 
     def _ensure_xbuf(self, D):
         if self._Xring is None or self._Xring.buf.shape[-1] != D:
             self._Xring = HistoryRing(self.K_HOPS, (self.N_ENVS, self.N_AGENTS, D), torch.float32, self.device,
-                                      self.HISTORY_SLOTS, pad="copy")
+                                      self.HISTORY_SLOTS, pad="copy", view_fn=self._stack_view)
             self.STATE_DIM = D
 
     # ------------------------------------------------------------------ observation / adjacency stacks
@@ -172,7 +179,7 @@ class MRS(_EnvBase):
         return self.get_Xk()
 
     def get_Xk(self):  # MRS.py:98-99  Xk: K+1 x N x D  (E x K+1 x N x D)
-        return self._squeeze(self._Xring.window().permute(1, 0, 2, 3))
+        return self._out(self._Xring.view())
 
     def calc_Ak(self):  # MRS.py:102-110
         slot = self._Apacked.next_slot()
@@ -189,7 +196,7 @@ class MRS(_EnvBase):
 
     def get_Ak(self):  # MRS.py:113-114  Ak: K+1 x N x N, missing slots are zeros (MRS.py:107-108)
         ring = self._Adense if self._Adense is not None else self._Apacked
-        return self._squeeze(ring.window().permute(1, 0, 2, 3))
+        return self._out(ring.view())
 
     def calc_A(self):  # MRS.py:117-124  newest adjacency only, no history side effect
         E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
@@ -371,24 +378,31 @@ class MRS(_EnvBase):
                 raise Exception('The given action contains NaN:\n %s' % str(actions))
             self.last_action = actions
             atype = ACTION_TYPE if ACTION_TYPE is not None else self.ACTION_TYPE
-            if atype not in native.ACT or atype is None:
+            at = native.ACT.get(atype, -1) if atype is not None else -1
+            if at <= 0:
                 raise AttributeError("'Quadcopter' object has no attribute %r" % (atype,))  # Environment.py:92
-        # env.set_actions + sim.step_sim + newest X slice + newest A rows: ONE fused launch
+            if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            if actions.numel() != E * N * native.ACT_DIM[at]:
+                raise ValueError("actions has %d elements, expected (%sN=%d, %d)" %
+                                 (actions.numel(), "" if E == 1 else "E=%d, " % E, N, native.ACT_DIM[at]))
+        else:
+            at = 0
+        # env.set_actions + sim.step_sim + newest X slice + newest A rows: one C-ABI call, raw slot pointers
         want_A = self.RETURN_A is None or bool(self.RETURN_A)
         fused = self._obs.fused
-        xslot = self._Xring.next_slot()
-        aslot = self._Apacked.next_slot() if want_A else None
-        self.shard.step(actions, atype,
-                        obs_out=self._Xring.buf[xslot] if fused else None,
-                        adj_out=self._Apacked.buf[aslot] if want_A else None,
-                        comm_range=self.COMM_RANGE)
+        xr, ar = self._Xring, self._Apacked
+        xslot = xr.next_slot()
+        aslot = ar.next_slot() if want_A else 0
+        self.shard.step_ptr(actions, at, xr.ptr(xslot) if fused else 0, ar.ptr(aslot) if want_A else 0,
+                            float(self.COMM_RANGE))
         if not fused:
-            self._obs.write_into(self._Xring.buf[xslot])
-        self._Xring.committed()
+            self._obs.write_into(xr.buf[xslot])
+        xr.committed()
         Xk = self.get_Xk()
         Ak = None
         if want_A:
-            self._Apacked.committed()
+            ar.committed()
             self._expand_newest_A()
             Ak = self.get_Ak()
         mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")

@@ -52,10 +52,11 @@ class MrsParams(C.Structure):
 
 class MrsBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pos", "quat", "vel", "angvel", "pid64", "pid32", "obs", "adj", "rpm", "status")]
+                ("pos", "quat", "vel", "angvel", "pid", "obs", "adj", "rpm", "status")]
 
 
 _lib = None
+_NAN = float("nan")
 
 
 class MrsNativeError(RuntimeError):
@@ -152,13 +153,15 @@ class SwarmShard:
         self.quat[3] = 1.0
         self.vel = torch.zeros(3, self.T, **f64)
         self.angvel = torch.zeros(3, self.T, **f64)
-        self.pid64 = torch.zeros(12, self.T, **f64)
-        self.pid32 = torch.full((6, self.T), float("nan"), dtype=torch.float32, device=device)
+        self.pid = torch.zeros(18, self.T, dtype=torch.float32, device=device)
+        self.pid[12:] = float("nan")          # last_vel_e / last_target_vel "attribute not created yet"
         self.status = torch.zeros(self.E, dtype=torch.int32, device=device)
         self.rpm = torch.zeros(4, self.T, dtype=torch.float32, device=device) if want_rpm else None
         self.set_obs_fields(obs_fields)
         self.adj = torch.zeros(self.E, self.N, self.W, dtype=torch.int64, device=device)
         self.obs = None
+        self._pb = self._buffers()
+        self._pb_ref = C.byref(self._pb)
 
     def __del__(self):
         try:
@@ -182,7 +185,7 @@ class SwarmShard:
     def _buffers(self, obs=None, adj=None):
         b = MrsBuffers()
         b.pos, b.quat, b.vel, b.angvel = self.pos.data_ptr(), self.quat.data_ptr(), self.vel.data_ptr(), self.angvel.data_ptr()
-        b.pid64, b.pid32 = self.pid64.data_ptr(), self.pid32.data_ptr()
+        b.pid = self.pid.data_ptr()
         b.obs = obs.data_ptr() if obs is not None else None
         b.adj = adj.data_ptr() if adj is not None else None
         b.rpm = self.rpm.data_ptr() if self.rpm is not None else None
@@ -254,6 +257,19 @@ class SwarmShard:
             raise AttributeError("'Quadcopter' object has no attribute %r" % (action_type,))   # Environment.py:92
         _check(rc, "mrs_step")
 
+    def step_ptr(self, actions, at, obs_ptr, adj_ptr, comm_range):
+        """Per-step fast path for MRS.step: `actions` is a contiguous float32 device tensor (or None),
+        `at` the integer ACTION_TYPE, obs_ptr / adj_ptr raw device addresses (0 = skip).  The MrsBuffers
+        struct is persistent (the state tensors are never reallocated); only two fields change per step."""
+        b = self._pb
+        b.obs = obs_ptr or None
+        b.adj = adj_ptr or None
+        rc = self.L.mrs_step(self.h, self._pb_ref, actions.data_ptr() if actions is not None else None, at, self.obs_codes,
+                             self.n_obs if obs_ptr else 0, comm_range if adj_ptr else _NAN,
+                             torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(rc, "mrs_step")
+
     def observe(self, obs_out):
         b = self._buffers(obs_out, None)
         _check(self.L.mrs_observe(self.h, C.byref(b), self.obs_codes, self.n_obs, _stream(self.device)), "mrs_observe")
@@ -282,8 +298,8 @@ class SwarmShard:
         return t.view(k, self.E, self.N).permute(1, 2, 0)
 
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in ("pos", "quat", "vel", "angvel", "pid64", "pid32")}
+        return {k: getattr(self, k).clone() for k in ("pos", "quat", "vel", "angvel", "pid")}
 
     def load_state_dict(self, sd):
-        for k in ("pos", "quat", "vel", "angvel", "pid64", "pid32"):
+        for k in ("pos", "quat", "vel", "angvel", "pid"):
             getattr(self, k).copy_(sd[k])

@@ -235,7 +235,7 @@ def test_large_n_and_ragged_blocks():
             a = acts(t)
             sh.step(torch.from_numpy(a).cuda(), atype, adj_out=adj, comm_range=5.0)
             sw.step(a, atype)
-        _compare(sh, sw, 1e-6, "E%d N%d %s" % (E, N, atype))
+        _compare(sh, sw, 2e-5, "E%d N%d %s" % (E, N, atype))
         sh.adjacency_expand(adj, dense)
         p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
         want = np.stack([oracle.adjacency(p32[e], 5.0) for e in range(E)])
