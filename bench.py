@@ -91,7 +91,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    dev = torch.device("cuda", local if world > 1 else 0)
+    # MRS_BENCH_SINGLE_DEVICE=1 (+ MRS_DIST_BACKEND=gloo): rehearse the N>1 code path on a one-GPU box
+    single = os.environ.get("MRS_BENCH_SINGLE_DEVICE") == "1"
+    dev = torch.device("cuda", local if (world > 1 and not single) else 0)
     torch.cuda.set_device(dev)
     E, N = args.envs_per_gpu, N_AGENTS
     base = rank * E

@@ -460,8 +460,29 @@ MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3
     }
     if (!active) return;
     float ln[8], lx[8], ly[8];
+    // effective masses and the normal rhs depend only on the pre-solve state: computed once per point
+    // (3 float64 divisions each) instead of once per point per sweep
+    double Kn[8], Kx[8], Ky[8], rhs[8];
+    const double rdt = 1.0 / P.dt;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ln[k] = 0.f; lx[k] = 0.f; ly[k] = 0.f; }
+    for (int k = 0; k < 8; ++k) {
+        ln[k] = 0.f; lx[k] = 0.f; ly[k] = 0.f;
+        Kn[k] = 0.; Kx[k] = 0.; Ky[k] = 0.; rhs[k] = 0.;
+        if (!(active & (1u << k))) continue;
+        const V3 r = v3(((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x),
+                        ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y),
+                        ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z));
+        const V3 un = v3(r.y, -r.x, 0.), ux = v3(0., r.z, -r.y), uy = v3(-r.z, 0., r.x);
+        const V3 In = symmul(Iw, un), Ix = symmul(Iw, ux), Iy = symmul(Iw, uy);
+        Kn[k] = 1.0 / (im + (un.x * In.x + un.y * In.y));
+        Kx[k] = 1.0 / (im + (ux.y * Ix.y + ux.z * Ix.z));
+        Ky[k] = 1.0 / (im + (uy.x * Iy.x + uy.z * Iy.z));
+        const double dist = pz + r.z - P.ground_z;
+        const double vrel0 = v.z + (w.x * r.y - w.y * r.x);
+        double poserr = 0., velerr = -vrel0;
+        if (dist > 0) velerr -= dist * rdt; else poserr = -dist * P.erp * rdt;
+        rhs[k] = poserr + velerr;
+    }
     const V3 v0 = v, w0 = w;
     for (int it = 0; it < P.solver_iters; ++it) {
 #pragma unroll
@@ -470,16 +491,12 @@ MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3
             const V3 r = v3(((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x),
                             ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y),
                             ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z));
-            const double dist = pz + r.z - P.ground_z;
             { // normal (+z): u = r x z = (r.y, -r.x, 0)
                 const V3 u = v3(r.y, -r.x, 0.);
                 const V3 Iu = symmul(Iw, u);
-                const double K = 1.0 / (im + (u.x * Iu.x + u.y * Iu.y));
-                const double vrel0 = v0.z + (w0.x * r.y - w0.y * r.x);
-                double poserr = 0., velerr = -vrel0;
-                if (dist > 0) velerr -= dist / P.dt; else poserr = -dist * P.erp / P.dt;
+                const double K = Kn[k];
                 const double dvn = (v.z - v0.z) + ((w.x - w0.x) * r.y - (w.y - w0.y) * r.x);
-                double nl = (double)ln[k] + K * ((poserr + velerr) - dvn);
+                double nl = (double)ln[k] + K * (rhs[k] - dvn);
                 nl = nl < 0 ? 0 : nl;
                 const double dl = nl - (double)ln[k];
                 ln[k] = (float)nl;
@@ -490,7 +507,7 @@ MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3
             { // friction x: u = r x x = (0, r.z, -r.y)
                 const V3 u = v3(0., r.z, -r.y);
                 const V3 Iu = symmul(Iw, u);
-                const double K = 1.0 / (im + (u.y * Iu.y + u.z * Iu.z));
+                const double K = Kx[k];
                 const double vt = v.x + (w.y * r.z - w.z * r.y);
                 const double nl = clampd((double)lx[k] - K * vt, -lim, lim);
                 const double dl = nl - (double)lx[k];
@@ -501,7 +518,7 @@ MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3
             { // friction y: u = r x y = (-r.z, 0, r.x)
                 const V3 u = v3(-r.z, 0., r.x);
                 const V3 Iu = symmul(Iw, u);
-                const double K = 1.0 / (im + (u.x * Iu.x + u.z * Iu.z));
+                const double K = Ky[k];
                 const double vt = v.y + (w.z * r.x - w.x * r.z);
                 const double nl = clampd((double)ly[k] - K * vt, -lim, lim);
                 const double dl = nl - (double)ly[k];

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
 {
     extern __shared__ float4 lds_tile[]; // BLOCK positions, then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + BLOCK);
+    int *ncontact = nanflag + 256; // bodies of this workgroup queued for k_contact
 
     const int tid = threadIdx.x;
     const int el = tid / A.N;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
     float act[4] = {0, 0, 0, 0};
     if (tid < A.epb) nanflag[tid] = 0;
+    if (tid == 0) *ncontact = 0;
     if (live) {
         load_state(A.b, a, T, p, q, v, w);
         if (ACT != MRS_ACT_NONE) {
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
     const bool doit = live && !masked && !(ACT != MRS_ACT_NONE && nanflag[el]);
     if (live && i == 0 && ACT != MRS_ACT_NONE && nanflag[el] && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
+    int my_slot = -1;
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
         // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane.
@@ -269,28 +272,41 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             const size_t Ts = T;
             A.b.vel[a] = v[0]; A.b.vel[Ts + a] = v[1]; A.b.vel[2 * Ts + a] = v[2];
             A.b.angvel[a] = w[0]; A.b.angvel[Ts + a] = w[1]; A.b.angvel[2 * Ts + a] = w[2];
-            const int slot = atomicAdd(A.contact_count, 1);
-            A.contact_list[slot] = (int)a;
+            my_slot = atomicAdd(ncontact, 1); // LDS counter: slot inside this workgroup's reservation
         } else {
             integrate_pose(A.P, p, q, v, w);
             store_state(A.b, a, T, p, q, v, w);
         }
     }
-    if (blockIdx.x == 0 && tid == 0) *A.contact_count_next = 0; // next step's counter (this one is read by k_contact)
+    // Two-level compaction into one global list: lanes take slots from an LDS counter, ONE lane per
+    // workgroup reserves the range with a single device-scope atomic (a per-wave atomic on one word
+    // serialises 4096 returning atomics at ~12 ns each and dominated the kernel once a third of the
+    // swarm was on the ground).
+    __syncthreads();
+    if (tid == 0) {
+        const int n = *ncontact;
+        ncontact[1] = n ? atomicAdd(A.contact_count, n) : 0;
+        if (blockIdx.x == 0) *A.contact_count_next = 0; // next step's counter (this one is read by k_contact)
+    }
+    __syncthreads();
+    if (my_slot >= 0) A.contact_list[ncontact[1] + my_slot] = (int)a;
 }
 
 // Contact pass over the compacted list written by k_step: ground contact + pose integration of the
 // queued bodies (BulletSim.step_sim's constraint solve + integrateTransforms for those bodies).
 __global__ __launch_bounds__(256) void k_contact(const StepArgs A)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= *A.contact_count) return;
-    const size_t a = (size_t)A.contact_list[idx], T = (size_t)A.T;
-    double p[3], q[4], v[3], w[3];
-    load_state(A.b, a, T, p, q, v, w);
-    contact_stage(A.P, p, q, v, w);
-    integrate_pose(A.P, p, q, v, w);
-    store_state(A.b, a, T, p, q, v, w);
+    const int count = *A.contact_count;
+    const size_t T = (size_t)A.T;
+    // fixed grid + stride: an empty list costs one quick wave per workgroup, a full one fills the chip
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const size_t a = (size_t)A.contact_list[idx];
+        double p[3], q[4], v[3], w[3];
+        load_state(A.b, a, T, p, q, v, w);
+        contact_stage(A.P, p, q, v, w);
+        integrate_pose(A.P, p, q, v, w);
+        store_state(A.b, a, T, p, q, v, w);
+    }
 }
 
 // standalone observe / adjacency (reset()/set() -> calc_Xk, DataGenerator's calc_Ak after reset)
@@ -305,7 +321,19 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
     const bool live = (el < A.epb) && (e < A.E);
     const size_t a = live ? (size_t)e * A.N + i : 0;
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
-    if (live) load_state(A.b, a, (size_t)A.T, p, q, v, w);
+    if (live) { // only the planes the observation spec names are moved (cat(pos, vel): 48 of the 104 bytes)
+        const size_t T = (size_t)A.T;
+        bool nq = false, nv = false, nw = false;
+        for (int f = 0; f < A.n_obs; ++f) {
+            nq |= (A.obs_fields[f] == MRS_OBS_EULER) || (A.obs_fields[f] == MRS_OBS_QUAT);
+            nv |= (A.obs_fields[f] == MRS_OBS_VEL);
+            nw |= (A.obs_fields[f] == MRS_OBS_ANGVEL);
+        }
+        p[0] = A.b.pos[a]; p[1] = A.b.pos[T + a]; p[2] = A.b.pos[2 * T + a];
+        if (nq) { q[0] = A.b.quat[a]; q[1] = A.b.quat[T + a]; q[2] = A.b.quat[2 * T + a]; q[3] = A.b.quat[3 * T + a]; }
+        if (nv) { v[0] = A.b.vel[a]; v[1] = A.b.vel[T + a]; v[2] = A.b.vel[2 * T + a]; }
+        if (nw) { w[0] = A.b.angvel[a]; w[1] = A.b.angvel[T + a]; w[2] = A.b.angvel[2 * T + a]; }
+    }
     if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
     if (A.do_adj) {
         lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
@@ -665,7 +693,7 @@ template <int ACT>
 static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st)
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
-    const size_t lds = (size_t)h->block * sizeof(float4) + 256 * sizeof(int);
+    const size_t lds = (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
     if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_step<ACT, 1024>), dim3(grid), dim3(1024), lds, st, A);
     return hipGetLastError();
@@ -684,7 +712,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
     if (rc) return rc;
     A.actions = actions;
-    // alternating counters: this step's k_step increments ws[parity] (read by this step's k_contact) and
+    // alternating counters: this step's k_step adds to ws[parity] (read by this step's k_contact) and
     // zeroes ws[parity^1] for the next step -- stream order makes that safe without a memset node
     A.contact_count = h->ws + (h->step_parity & 1);
     A.contact_count_next = h->ws + ((h->step_parity & 1) ^ 1);
@@ -705,7 +733,8 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     if (h->P.enable_contact) {
         // worst-case grid; blocks beyond the device-side count return at once
         const int T = h->E * h->N;
-        hipLaunchKernelGGL(k_contact, dim3((T + 255) / 256), dim3(256), 0, st, A);
+        const int blocks = (T + 255) / 256 < 1024 ? (T + 255) / 256 : 1024;
+        hipLaunchKernelGGL(k_contact, dim3(blocks), dim3(256), 0, st, A);
         e = hipGetLastError();
         if (e != hipSuccess) return hipfail(e, "mrs_step contact launch");
     }
