@@ -294,7 +294,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
 
 // Contact pass over the compacted list written by k_step: ground contact + pose integration of the
 // queued bodies (BulletSim.step_sim's constraint solve + integrateTransforms for those bodies).
-__global__ __launch_bounds__(256) void k_contact(const StepArgs A)
+#ifndef MRS_CONTACT_WAVES
+#define MRS_CONTACT_WAVES 2 // measured: capping VGPRs for 4+ resident waves spills the unrolled solver (4x slower)
+#endif
+__global__ __launch_bounds__(256, MRS_CONTACT_WAVES) void k_contact(const StepArgs A)
 {
     const int count = *A.contact_count;
     const size_t T = (size_t)A.T;
