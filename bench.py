@@ -168,7 +168,7 @@ def main():
     tp = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes (see profiles/README.md)
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("k_step_set_target_vel_bytes_per_launch")
+            traffic = json.load(open(tp)).get("mrs_step_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
