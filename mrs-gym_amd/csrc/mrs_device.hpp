@@ -406,6 +406,17 @@ MRS_DEV float downwash_pair_fast(float rx, float ry, float dz, const DownwashCon
     const float f = -(alpha * ex);
     return (dz > 0.f && d2 < 100.f) ? f : 0.f;   // Quadcopter.py:105: delta_z > 0 and delta_xy < 10
 }
+// The pair term as a function of (dxy^2, |dz|) only -- it is applied to whichever quadcopter of the
+// pair is lower (Quadcopter.py:105: delta_z > 0), so one evaluation serves both orderings.
+MRS_DEV float downwash_mag(float rx, float ry, float adz, const DownwashConst &c)
+{
+    const float d2 = rx * rx + ry * ry;
+    const float rdz = __builtin_amdgcn_rcpf(adz);
+    const float rb = __builtin_amdgcn_rcpf(c.dw2 * adz + c.dw3);
+    const float alpha = c.c_alpha * (rdz * rdz);
+    const float ex = __builtin_amdgcn_exp2f((-0.5f * 1.44269504088896341f) * (d2 * (rb * rb)));
+    return (adz > 0.f && d2 < 100.f) ? -(alpha * ex) : 0.f;
+}
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
 {
     const float dxy = f32sqrt(f32add(f32mul(rx, rx), f32mul(ry, ry))); // np.linalg.norm(rel[:2])

@@ -146,56 +146,87 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             const float4 *tile_env = lds_tile + el * A.N;
             const DownwashConst dc = downwash_const(A.P);
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
+#if !MRS_EXACT_F32
+            if (BLOCK == 256 && A.N == 64) {
+                // N = 64: the env is exactly this wave.  The pair term depends only on (|dz|, dxy^2) and lands
+                // on the LOWER quadcopter of the pair, so each unordered pair is evaluated once: lane i takes
+                // the pairs (i, i+k), k = 1..31, keeps the term if the other is above, and hands it to lane
+                // i+k (one ds_bpermute) if the other is below; k = 32 pairs lanes with their antipode, each
+                // side evaluating its own.  32 evaluations per lane instead of 64.  (`doit` is uniform per
+                // env, so the whole wave is here.)
+                const int lane = tid & 63;
 #pragma unroll 4
-            for (int j = 0; j < A.N; ++j) {
-                const float4 pj = tile_env[j];
-#if MRS_EXACT_F32
-                const float f = downwash_pair(f32sub(pj.x, mx), f32sub(pj.y, my), f32sub(pj.z, mz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
-#else
-                const float f = downwash_pair_fast(pj.x - mx, pj.y - my, pj.z - mz, dc);
+                for (int k = 1; k < 32; ++k) {
+                    const float4 pj = tile_env[(lane + k) & 63];
+                    const float dz = pj.z - mz;
+                    const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc);
+                    const float f_other = dz < 0.f ? F : 0.f;
+                    const float f_in = __shfl(f_other, (lane - k) & 63);
+                    downwash_acc += (double)((dz > 0.f ? F : 0.f) + f_in);
+                }
+                const float4 pj = tile_env[(lane + 32) & 63];
+                const float dz = pj.z - mz;
+                downwash_acc += (double)(dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f);
+            } else
 #endif
-                downwash_acc += (double)f;
+            {
+#pragma unroll 4
+                for (int j = 0; j < A.N; ++j) {
+                    const float4 pj = tile_env[j];
+#if MRS_EXACT_F32
+                    const float f = downwash_pair(f32sub(pj.x, mx), f32sub(pj.y, my), f32sub(pj.z, mz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
+#else
+                    const float f = downwash_pair_fast(pj.x - mx, pj.y - my, pj.z - mz, dc);
+#endif
+                    downwash_acc += (double)f;
+                }
             }
         }
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
-            Observed ob;
-            observe<true, true>(p, q, v, w, ob);
             double rpm[4];
             constexpr bool NEEDS_PID = (ACT >= MRS_ACT_TARGET_ACCEL);
-            if (NEEDS_PID) {
-                // controller memory: only the planes this ACTION_TYPE touches are moved (set_target_vel 15
-                // words, set_target_pos 6, set_target_accel / set_target_ori 3)
-                Pid s = {};
-                const float *g = A.b.pid + a;
-                if (ACT == MRS_ACT_TARGET_POS) { s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T]; }
-                if (ACT == MRS_ACT_TARGET_VEL) {
+            // Outer loops of the cascade first (QuadControl.pos_control / vel_control up to target_accel):
+            // they need only the float32 velocity/position read-back, so their 6..12 PID planes are loaded,
+            // used and stored BEFORE the register-hungry attitude part -- this is what lets
+            // k_step<set_target_vel> fit the 128 VGPRs of 4 resident waves per SIMD.
+            Pid s = {};
+            V3 ta = v3(0., 0., 0.);
+            if (ACT == MRS_ACT_TARGET_VEL || ACT == MRS_ACT_TARGET_POS) {
+                Observed o0;
+                observe<false, false>(p, q, v, w, o0);
+                float *g = A.b.pid + a;
+                if (ACT == MRS_ACT_TARGET_POS) {
+                    s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T];
+                    ta = pos_control_accel(P, s, o0, act[0], act[1], act[2]);
+                    g[0] = (float)s.ipx; g[T] = (float)s.ipy; g[2 * T] = (float)s.ipz;
+                } else {
                     s.dvx = g[3 * T]; s.dvy = g[4 * T]; s.dvz = g[5 * T];
                     s.ivx = g[6 * T]; s.ivy = g[7 * T]; s.ivz = g[8 * T];
                     s.lvx = g[12 * T]; s.lvy = g[13 * T]; s.lvz = g[14 * T];
                     s.ltx = g[15 * T]; s.lty = g[16 * T]; s.ltz = g[17 * T];
+                    ta = vel_control_accel(P, s, o0, act[0], act[1], act[2]);
+                    g[3 * T] = (float)s.dvx; g[4 * T] = (float)s.dvy; g[5 * T] = (float)s.dvz;
+                    g[6 * T] = (float)s.ivx; g[7 * T] = (float)s.ivy; g[8 * T] = (float)s.ivz;
+                    g[12 * T] = s.lvx; g[13 * T] = s.lvy; g[14 * T] = s.lvz;
+                    g[15 * T] = s.ltx; g[16 * T] = s.lty; g[17 * T] = s.ltz;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Observed ob;
+            observe<true, true>(p, q, v, w, ob);
+            if (NEEDS_PID) {
+                float *g = A.b.pid + a;
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
                 const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
                     attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
                 } else {
-                    V3 ta;
-                    if (ACT == MRS_ACT_TARGET_VEL) ta = vel_control_accel(P, s, ob, act[0], act[1], act[2]);
-                    else if (ACT == MRS_ACT_TARGET_POS) ta = pos_control_accel(P, s, ob, act[0], act[1], act[2]);
-                    else ta = v3((double)act[0], (double)act[1], (double)act[2]);
+                    if (ACT == MRS_ACT_TARGET_ACCEL) ta = v3((double)act[0], (double)act[1], (double)act[2]);
                     accel_control(P, A.rc, s, ta, R, ob, rpm);
                 }
-                float *go = A.b.pid + a;
-                if (ACT == MRS_ACT_TARGET_POS) { go[0] = (float)s.ipx; go[T] = (float)s.ipy; go[2 * T] = (float)s.ipz; }
-                if (ACT == MRS_ACT_TARGET_VEL) {
-                    go[3 * T] = (float)s.dvx; go[4 * T] = (float)s.dvy; go[5 * T] = (float)s.dvz;
-                    go[6 * T] = (float)s.ivx; go[7 * T] = (float)s.ivy; go[8 * T] = (float)s.ivz;
-                    go[12 * T] = s.lvx; go[13 * T] = s.lvy; go[14 * T] = s.lvz;
-                    go[15 * T] = s.ltx; go[16 * T] = s.lty; go[17 * T] = s.ltz;
-                }
-                go[9 * T] = (float)s.iox; go[10 * T] = (float)s.ioy; go[11 * T] = (float)s.ioz;
+                g[9 * T] = (float)s.iox; g[10 * T] = (float)s.ioy; g[11 * T] = (float)s.ioz;
             } else if (ACT == MRS_ACT_SET_CONTROL) {
                 set_control(P, act[0], act[1], act[2], act[3], rpm);
             } else {
@@ -341,7 +372,34 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
     if (A.do_adj) {
         lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
         __syncthreads();
-        if (live) adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+        if (BLOCK == 256 && A.N == 64) {
+            // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
+            // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
+            // k = 1..31, sets bit i+k in its own row and passes the verdict to lane i+k (ds_bpermute) for
+            // bit i of that row; k = 32 is tested by both ends.
+            if (live) {
+                const int lane = tid & 63;
+                const float4 *tile_env = lds_tile + el * 64;
+                const float4 me = lds_tile[tid];
+                uint64_t bits = 0;
+#pragma unroll 4
+                for (int k = 1; k <= 32; ++k) {
+                    const int jl = (lane + k) & 63;
+                    const float4 pj = tile_env[jl];
+                    const float dx = f32sub(me.x, pj.x), dy = f32sub(me.y, pj.y), dz = f32sub(me.z, pj.z);
+                    const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
+                    const int close = A.comm_inf ? 1 : (d2 <= A.d2_thresh);
+                    bits |= (uint64_t)close << jl;
+                    if (k < 32) {
+                        const int il = (lane - k) & 63;
+                        bits |= (uint64_t)__shfl(close, il) << il;
+                    }
+                }
+                A.b.adj[a] = bits;
+            }
+        } else if (live) {
+            adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+        }
     }
 }
 
