@@ -98,8 +98,11 @@ template <int ACT, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_step(const StepArgs A)
 {
     extern __shared__ float4 lds_tile[]; // BLOCK positions, then one int flag per env slot
-    int *nanflag = reinterpret_cast<int *>(lds_tile + BLOCK);
+    int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
     int *ncontact = nanflag + 256; // bodies of this workgroup queued for k_contact
+    // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
+    // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
+    const bool n64 = (BLOCK == 256) && (A.N == 64);
 
     const int tid = threadIdx.x;
     const int el = tid / A.N;
@@ -121,7 +124,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             for (int k = 0; k < ADIM; ++k) act[k] = A.actions[a * ADIM + k];
         }
     }
-    lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    if (n64) {
+        lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    } else {
+        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    }
     __syncthreads();
     if (live && ACT != MRS_ACT_NONE) {
         bool bad = false;
@@ -155,18 +162,25 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
                 // side evaluating its own.  32 evaluations per lane instead of 64.  (`doit` is uniform per
                 // env, so the whole wave is here.)
                 const int lane = tid & 63;
-#pragma unroll 4
+                const float4 *nb = lds_tile + el * 128 + lane; // nb[k] = neighbour (lane + k) mod 64, no wrap
+                const int lane4 = lane << 2;                     // ds_bpermute byte address of this lane
+                float acc32 = 0.f;
+#pragma unroll
                 for (int k = 1; k < 32; ++k) {
-                    const float4 pj = tile_env[(lane + k) & 63];
+                    const float4 pj = nb[k];
                     const float dz = pj.z - mz;
-                    const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc);
-                    const float f_other = dz < 0.f ? F : 0.f;
-                    const float f_in = __shfl(f_other, (lane - k) & 63);
-                    downwash_acc += (double)((dz > 0.f ? F : 0.f) + f_in);
+                    const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc); // 0 when dz == 0
+                    const bool above = dz > 0.f;
+                    const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
+                    // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
+                    const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
+                    acc32 += f_self + f_in;
+                    if ((k & 7) == 0) { downwash_acc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
                 }
-                const float4 pj = tile_env[(lane + 32) & 63];
+                const float4 pj = nb[32];
                 const float dz = pj.z - mz;
-                downwash_acc += (double)(dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f);
+                acc32 += dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f;
+                downwash_acc += (double)acc32;
             } else
 #endif
             {
@@ -370,32 +384,37 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
     }
     if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
     if (A.do_adj) {
-        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+        const bool n64 = (BLOCK == 256) && (A.N == 64);
+        const float4 mine = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+        if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
+        else lds_tile[tid] = mine;
         __syncthreads();
-        if (BLOCK == 256 && A.N == 64) {
+        if (n64) {
             // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
             // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
-            // k = 1..31, sets bit i+k in its own row and passes the verdict to lane i+k (ds_bpermute) for
-            // bit i of that row; k = 32 is tested by both ends.
+            // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
+            // it is relative bit 64-k; k = 32 is tested by both ends.  All shifts are immediates on 32-bit
+            // halves; one 64-bit rotate by the lane index at the end turns relative into absolute columns.
             if (live) {
                 const int lane = tid & 63;
-                const float4 *tile_env = lds_tile + el * 64;
-                const float4 me = lds_tile[tid];
-                uint64_t bits = 0;
-#pragma unroll 4
+                const float4 *nb = lds_tile + el * 128 + lane;
+                const int lane4 = lane << 2;
+                uint32_t lo = 0, hi = 0; // relative bits 1..31 in lo, 32..63 in hi
+#pragma unroll
                 for (int k = 1; k <= 32; ++k) {
-                    const int jl = (lane + k) & 63;
-                    const float4 pj = tile_env[jl];
-                    const float dx = f32sub(me.x, pj.x), dy = f32sub(me.y, pj.y), dz = f32sub(me.z, pj.z);
+                    const float4 pj = nb[k];
+                    const float dx = f32sub(mine.x, pj.x), dy = f32sub(mine.y, pj.y), dz = f32sub(mine.z, pj.z);
                     const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
-                    const int close = A.comm_inf ? 1 : (d2 <= A.d2_thresh);
-                    bits |= (uint64_t)close << jl;
+                    const uint32_t close = A.comm_inf ? 1u : (uint32_t)(d2 <= A.d2_thresh);
                     if (k < 32) {
-                        const int il = (lane - k) & 63;
-                        bits |= (uint64_t)__shfl(close, il) << il;
+                        lo |= close << k;
+                        hi |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)close) << (32 - k);
+                    } else {
+                        hi |= close; // relative bit 32
                     }
                 }
-                A.b.adj[a] = bits;
+                const uint64_t rel = ((uint64_t)hi << 32) | lo;
+                A.b.adj[a] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
             }
         } else if (live) {
             adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
@@ -754,7 +773,7 @@ template <int ACT>
 static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st)
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
-    const size_t lds = (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
+    const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
     if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_step<ACT, 1024>), dim3(grid), dim3(1024), lds, st, A);
     return hipGetLastError();
@@ -806,7 +825,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
 static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
-    const size_t lds = (size_t)h->block * sizeof(float4);
+    const size_t lds = 2 * (size_t)h->block * sizeof(float4);
     if (h->block == 256) hipLaunchKernelGGL((k_observe_adj<256>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_observe_adj<1024>), dim3(grid), dim3(1024), lds, st, A);
     hipError_t e = hipGetLastError();
