@@ -122,8 +122,9 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     # HIP events bracket every step-kernel launch on the stream it is launched on (torch's current stream)
-    # (every EV_EVERY-th step: an event pair is two more nodes in the stream and costs the timed loop ~2 %)
-    EV_EVERY = 8
+    # (every EV_EVERY-th step: on this stack a timing-event pair costs the stream ~60 us -- measured 137 us
+    # per step with a pair on every step against 76 us with none -- so the kernel time is SAMPLED)
+    EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
     shard_step = env.shard.step_ptr

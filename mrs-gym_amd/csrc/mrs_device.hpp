@@ -69,7 +69,26 @@ MRS_DEV V3 mulT(const M3 &R, V3 v)
     return V3{R.m00 * v.x + R.m10 * v.y + R.m20 * v.z, R.m01 * v.x + R.m11 * v.y + R.m21 * v.z,
               R.m02 * v.x + R.m12 * v.y + R.m22 * v.z};
 }
-MRS_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// v_max_f64 / v_min_f64: two instructions instead of two compares and four 32-bit selects
+MRS_DEV double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// Reciprocal and reciprocal square root to ~1 ulp: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) plus
+// two Newton steps (5 / 9 instructions) instead of the ~14-instruction correctly rounded division and
+// the sqrt + division pair.  Arguments here are norms and cosines: positive, normal, finite.
+MRS_DEV double rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+}
+MRS_DEV double rsqrt64(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x, y * y, 1.5);
+    y = y * __builtin_fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
 
 // ---- float64 trigonometry sized for this kernel -------------------------------------------------
 // Euler angles live in [-pi, pi] and the integrator's half-angle in [0, pi/8], so the general
@@ -118,7 +137,7 @@ MRS_DEV double fast_atan2(double y, double x)
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
     if (!(mx > 0.0) || !(mx < 1e300)) return atan2(y, x);                 // zeros / inf / NaN: library semantics
     const bool red = mn > 0.41421356237309503 * mx;
-    const double t = (red ? mn - mx : mn) / (red ? mn + mx : mx);
+    const double t = (red ? mn - mx : mn) * rcp64(red ? mn + mx : mx);
     double a = katan(t);
     if (red) a = (a + 3.06161699786838301793e-17) + 7.85398163397448278999e-01;      // + pi/4 (lo, hi)
     if (ay > ax) a = (6.12323399573676603587e-17 - a) + 1.57079632679489655800e+00;  // pi/2 - a
@@ -129,8 +148,7 @@ MRS_DEV double fast_atan2(double y, double x)
 // scipy Rotation.as_matrix of the normalised quaternion (Object.py:93-95)
 MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
 {
-    const double n = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
-    const double rn = 1.0 / n;
+    const double rn = rsqrt64(qx * qx + qy * qy + qz * qz + qw * qw);
     const double x = qx * rn, y = qy * rn, z = qz * rn, w = qw * rn;
     const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
     const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
@@ -145,7 +163,7 @@ MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
 MRS_DEV M3 quat_to_matrix_bullet(double qx, double qy, double qz, double qw)
 {
     const double d = qx * qx + qy * qy + qz * qz + qw * qw;
-    const double s = 2.0 / d;
+    const double s = 2.0 * rcp64(d);
     const double xs = qx * s, ys = qy * s, zs = qz * s;
     const double wx = qw * xs, wy = qw * ys, wz = qw * zs;
     const double xx = qx * xs, xy = qx * ys, xz = qx * zs;
@@ -262,9 +280,9 @@ MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const
     const double nta = norm(ta);
     double thrust = 0.;
     if (nta != 0) { // :117-122
-        const double rn = 1.0 / nta;
+        const double rn = rcp64(nta);
         const double cosang = (ta.x * rn) * R.m02 + (ta.y * rn) * R.m12 + (ta.z * rn) * R.m22;
-        thrust = (1 / (cosang > 0.2 ? cosang : 0.2)) * nta * P.mass;
+        thrust = rcp64(cosang > 0.2 ? cosang : 0.2) * nta * P.mass;
     }
     const double tp = (sqrt(thrust * K.inv_4kf) - 4070.3) * (1.0 / 0.2685); // :123 (host-side reciprocals)
     // MixerMatrix (:27) rows (.5,-.5,-1) (.5,.5,1) (-.5,.5,-1) (-.5,-.5,1); clip [20000,65535]; rpm = .2685 pwm + 4070.3
@@ -279,8 +297,8 @@ MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in
                            double rpm[4])
 {
     const V3 ta = v3(ta_in.x + 0., ta_in.y + 0., ta_in.z + P.ctrl_gravity); // :76
-    const double rn = 1.0 / norm(ta);
-    V3 tz = v3(ta.x * rn, ta.y * rn, ta.z * rn); // :78 (|ta| = 0 -> 0 * inf = NaN -> next line)
+    const double rn = rsqrt64(dot(ta, ta));
+    V3 tz = v3(ta.x * rn, ta.y * rn, ta.z * rn); // :78 (|ta| = 0 -> rsq = inf, 0 * inf = NaN -> next line)
     if (isnan(tz.x) || isnan(tz.y) || isnan(tz.z)) tz = v3(0., 0., 1.); // :79-80
     // :77 rotation is cast to float32; :82 x_t = R[:,1] x z_t (not normalised); :83 y_t = z_t x x_t
     const V3 ycol = v3((double)(float)R.m01, (double)(float)R.m11, (double)(float)R.m21);
@@ -290,7 +308,7 @@ MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in
     // normalisation (columns are mutually orthogonal); :100 rebuilds the same matrix from its euler angles.
     // z_t is a unit vector and y_t = z_t x x_t is orthogonal to it, so |y_t| = |x_t| and |z_t| = 1 up to
     // one rounding: one reciprocal norm serves all three columns.
-    const double nx = 1.0 / norm(tx);
+    const double nx = rsqrt64(dot(tx, tx));
     M3 Rt;
     Rt.m00 = tx.x * nx; Rt.m10 = tx.y * nx; Rt.m20 = tx.z * nx;
     Rt.m01 = ty.x * nx; Rt.m11 = ty.y * nx; Rt.m21 = ty.z * nx;
@@ -705,15 +723,14 @@ MRS_DEV void integrate_pose(const MrsParams &P, double p[3], double q[4], const 
     if (fAngle < 0.001)
         sc = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle;
     else
-        sc = ksin(0.5 * fAngle * dt) / fAngle;   // half-angle <= pi/8 after the threshold above: kernel range
+        sc = ksin(0.5 * fAngle * dt) * rcp64(fAngle);   // half-angle <= pi/8 after the threshold above: kernel range
     const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc, dw = kcos(fAngle * dt * 0.5);
     const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
     const double nx = dw * qx + ax * qw + ay * qz - az * qy;
     const double ny = dw * qy + ay * qw + az * qx - ax * qz;
     const double nz = dw * qz + az * qw + ax * qy - ay * qx;
     const double nw2 = dw * qw - ax * qx - ay * qy - az * qz;
-    const double nn = sqrt(nx * nx + ny * ny + nz * nz + nw2 * nw2);
-    const double rnn = 1.0 / nn;
+    const double rnn = rsqrt64(nx * nx + ny * ny + nz * nz + nw2 * nw2);
     q[0] = nx * rnn; q[1] = ny * rnn; q[2] = nz * rnn; q[3] = nw2 * rnn;
 }
 
