@@ -485,7 +485,8 @@ MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const double rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z);
-        if (pz + rz - P.ground_z <= P.contact_threshold) active |= 1u << k;
+        const bool lower_cap = (R.m22 >= 0) ? ((k & 4) != 0) : ((k & 4) == 0); // only the cap facing the ground
+        if (lower_cap && pz + rz - P.ground_z <= P.contact_threshold) active |= 1u << k;
     }
     if (!active) return;
     float ln[8], lx[8], ly[8];
@@ -622,21 +623,24 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
     const float Ixx = r00 * r00 * i0 + r01 * r01 * i1 + r02 * r02 * i2, Ixy = r00 * r10 * i0 + r01 * r11 * i1 + r02 * r12 * i2,
                 Ixz = r00 * r20 * i0 + r01 * r21 * i1 + r02 * r22 * i2, Iyy = r10 * r10 * i0 + r11 * r11 * i1 + r12 * r12 * i2,
                 Iyz = r10 * r20 * i0 + r11 * r21 * i1 + r12 * r22 * i2, Izz = r20 * r20 * i0 + r21 * r21 * i1 + r22 * r22 * i2;
-    const double cxz = c * R.m20, cyz = c * R.m21, czz = hl * R.m22; // z of the rim points in float64 (gap cancellation)
+    const double cxz = c * R.m20, cyz = c * R.m21; // z of the rim points in float64 (gap cancellation)
+    // only the rim of the cap facing the ground carries contacts (oracle: lower_cap): fold its sign into cz
+    const double sgn = (R.m22 >= 0) ? -1.0 : 1.0;
+    const double czz = sgn * (hl * R.m22);
     const F3 cx = {(float)(c * R.m00), (float)(c * R.m10), (float)cxz}, cy = {(float)(c * R.m01), (float)(c * R.m11), (float)cyz},
-             cz = {(float)(hl * R.m02), (float)(hl * R.m12), (float)czz};
+             cz = {(float)(sgn * hl * R.m02), (float)(sgn * hl * R.m12), (float)czz};
     unsigned active = 0;
-    float ln[8], lx[8], ly[8], Kn[8], Kx[8], Ky[8], rhs[8];
+    float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
     const double rdt = 1.0 / P.dt;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
         ln[k] = lx[k] = ly[k] = Kn[k] = Kx[k] = Ky[k] = rhs[k] = 0.f;
-        const double rzd = ((k & 1) ? -cxz : cxz) + ((k & 2) ? -cyz : cyz) + ((k & 4) ? -czz : czz);
+        const double rzd = ((k & 1) ? -cxz : cxz) + ((k & 2) ? -cyz : cyz) + czz;
         const double dist = pz + rzd - P.ground_z;
         if (!(dist <= P.contact_threshold)) continue;
         active |= 1u << k;
-        const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x);
-        const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y);
+        const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
+        const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
         const float rz = (float)rzd;
         // u^T Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
         Kn[k] = __builtin_amdgcn_rcpf(im + (ry * (Ixx * ry - Ixy * rx) - rx * (Ixy * ry - Iyy * rx)));
@@ -658,11 +662,11 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
     for (int it = 0; it < P.solver_iters; ++it) {
         float moved = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (!(active & (1u << k))) continue;
-            const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x);
-            const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y);
-            const float rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z);
+            const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
+            const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
+            const float rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + cz.z;
             { // normal: u = (ry, -rx, 0)
                 const float dvn = dvz + (dwx * ry - dwy * rx);
                 float nl = ln[k] + Kn[k] * (rhs[k] - dvn);

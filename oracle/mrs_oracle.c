@@ -484,7 +484,8 @@ static void matTvec(const double R[9], const double v[3], double o[3])
 }
 
 /* Ground contact: the build's own model (Bullet's GJK/EPA persistent manifold + PGS is not
- * reproducible).  8 body-fixed points on the rims of the collision cylinder,
+ * reproducible).  4 body-fixed points (azimuths 45+90k deg) on the rim of whichever
+ * cap of the collision cylinder faces the ground,
  * Bullet-style velocity-level rhs (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint),
  * sequential impulses with a friction pyramid along world x/y. */
 static void contact_solve(const OrcParams *p, const double pos[3], const double R[9], double v[3], double w[3])
@@ -499,7 +500,11 @@ static void contact_solve(const OrcParams *p, const double pos[3], const double 
         double pb[3] = {(k & 1) ? -c : c, (k & 2) ? -c : c, (k & 4) ? -p->coll_half_len : p->coll_half_len};
         matvec(R, pb, r[k]);
         dist[k] = pos[2] + r[k][2] - p->ground_z;
-        active[k] = dist[k] <= p->contact_threshold;
+        /* only the rim of the cap that faces the ground carries contacts: at every azimuth the other cap's
+         * point is 2 h |R22| higher, it can only come within the threshold once the body is tilted by more
+         * than ~37 degrees, where the lower rim already supports it */
+        const int lower_cap = (R[8] >= 0) ? ((k & 4) != 0) : ((k & 4) == 0);
+        active[k] = lower_cap && dist[k] <= p->contact_threshold;
         lam_n[k] = 0; lam_t[k][0] = 0; lam_t[k][1] = 0;
         if (!active[k]) continue;
         nact++;
