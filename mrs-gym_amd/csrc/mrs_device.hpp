@@ -58,7 +58,9 @@ MRS_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 MRS_DEV V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 MRS_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MRS_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-MRS_DEV double norm(V3 a) { return sqrt(dot(a, a)); }
+MRS_DEV double rsqrt64(double x);
+MRS_DEV double sqrt64(double s) { return s > 0.0 ? s * rsqrt64(s) : 0.0; } // ~1 ulp, 11 instructions
+MRS_DEV double norm(V3 a) { return sqrt64(dot(a, a)); }
 MRS_DEV V3 mul(const M3 &R, V3 v)
 {
     return V3{R.m00 * v.x + R.m01 * v.y + R.m02 * v.z, R.m10 * v.x + R.m11 * v.y + R.m12 * v.z,
@@ -181,7 +183,7 @@ MRS_DEV void matrix_to_euler(const M3 &R, double &roll, double &pitch, double &y
     // pitch = asin(-R20) written as atan2(-R20, cos(pitch)) with cos(pitch) = |(R21, R22)| taken from the
     // matrix itself (no 1 - s^2 cancellation near +-pi/2)
     roll = fast_atan2(R.m21, R.m22);
-    pitch = fast_atan2(-R.m20, sqrt(R.m21 * R.m21 + R.m22 * R.m22));
+    pitch = fast_atan2(-R.m20, sqrt64(R.m21 * R.m21 + R.m22 * R.m22));
     yaw = fast_atan2(R.m10, R.m00);
 }
 
@@ -284,7 +286,7 @@ MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const
         const double cosang = (ta.x * rn) * R.m02 + (ta.y * rn) * R.m12 + (ta.z * rn) * R.m22;
         thrust = rcp64(cosang > 0.2 ? cosang : 0.2) * nta * P.mass;
     }
-    const double tp = (sqrt(thrust * K.inv_4kf) - 4070.3) * (1.0 / 0.2685); // :123 (host-side reciprocals)
+    const double tp = (sqrt64(thrust * K.inv_4kf) - 4070.3) * (1.0 / 0.2685); // :123 (host-side reciprocals)
     // MixerMatrix (:27) rows (.5,-.5,-1) (.5,.5,1) (-.5,.5,-1) (-.5,-.5,1); clip [20000,65535]; rpm = .2685 pwm + 4070.3
     rpm[0] = 0.2685 * clampd(tp + (.5 * tx - .5 * ty - tz), 20000., 65535.) + 4070.3;
     rpm[1] = 0.2685 * clampd(tp + (.5 * tx + .5 * ty + tz), 20000., 65535.) + 4070.3;
@@ -721,7 +723,7 @@ MRS_DEV void integrate_pose(const MrsParams &P, double p[3], double q[4], const 
 {
     const double dt = P.dt;
     p[0] += dt * v[0]; p[1] += dt * v[1]; p[2] += dt * v[2];
-    double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double fAngle = sqrt64(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (fAngle * dt > 0.25 * kPi) fAngle = 0.5 * (0.5 * kPi) / dt;
     double sc;
     if (fAngle < 0.001)

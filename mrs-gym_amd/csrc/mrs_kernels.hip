@@ -285,7 +285,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             for (int k = 0; k < 4; ++k) {
                 double h = p[2] + (Rb.m20 * P.prop_x[k] + Rb.m21 * P.prop_y[k] + Rb.m22 * P.prop_z[k]);
                 h = h < A.hclip ? A.hclip : h; // :77
-                const double ratio = P.prop_radius / (4 * h);
+                const double ratio = P.prop_radius * rcp64(4 * h); // h >= hclip > 0
                 double g;
                 if (ACT == MRS_ACT_SET_SPEEDS) {
                     const float sq = f32mul(s32[k], s32[k]);
