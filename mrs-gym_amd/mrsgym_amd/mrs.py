@@ -231,37 +231,34 @@ class MRS(_EnvBase):
         sp = self.START_POS
         if isinstance(sp, torch.Tensor):
             return sp if sp.dim() == 3 else sp.unsqueeze(0).expand(E, N, 3)
-        out = []
+        # user distribution: per-agent (3,) samples or joint (N,3) samples; greedy re-sampling of the most
+        # colliding agents until every pair is >= 2*AGENT_RADIUS apart (same rule as k_spawn, one env at a time)
+        per_agent = sp.sample().dim() == 1
+        draw = (lambda: torch.stack([sp.sample() for _ in range(N)])) if per_agent else sp.sample
+        min_d = 2 * self.AGENT_RADIUS
+        envs = []
         for _ in range(E):
-            startpos = sp.sample()
-            one = False
-            if len(startpos.shape) == 1:
-                startpos = torch.stack([sp.sample() for _ in range(N)], dim=0)
-                one = True
-            codist = self.get_relative_position(startpos).norm(dim=2)
-            codist.diagonal().fill_(float('inf'))
-            while torch.any(codist < 2 * self.AGENT_RADIUS):
-                collisions = codist < 2 * self.AGENT_RADIUS
-                idxs = []
-                while torch.sum(collisions) != 0:
-                    idx = torch.mode(torch.where(collisions)[0])[0]
-                    idxs.append(idx)
-                    collisions[idx, :] = 0
-                    collisions[:, idx] = 0
-                idxs = torch.tensor(idxs)
-                if one:
-                    for idx in idxs:
-                        startpos[idx, :] = sp.sample()
-                else:
-                    new = sp.sample()
-                    startpos[idxs, :] = new[idxs, :]
-                codist = self.get_relative_position(startpos).norm(dim=2)
-                codist.diagonal().fill_(float('inf'))
-            out.append(startpos)
-        return torch.stack(out, 0)
+            pts = draw().clone()
+            while True:
+                close = torch.cdist(pts, pts) < min_d
+                close.fill_diagonal_(False)
+                if not bool(close.any()):
+                    break
+                redo = []
+                while bool(close.any()):
+                    worst = int(close.sum(dim=1).argmax())     # most collisions, lowest index on ties
+                    redo.append(worst)
+                    close[worst, :] = False
+                    close[:, worst] = False
+                fresh = draw()
+                pts[redo] = fresh[redo]
+            envs.append(pts)
+        return torch.stack(envs, 0)
 
     def generate_start_ori(self):  # MRS.py:157-161
         so = torch.as_tensor(self.START_ORI)
+        if so.dim() == 1:   # README.md:75-77: a (3) / (6) tensor applies to every agent
+            so = so.expand(self.N_AGENTS, -1)
         if so.shape[-1] == 3:
             return so
         lo, hi = so[..., :3].to(torch.float32), so[..., 3:].to(torch.float32)

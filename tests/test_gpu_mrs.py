@@ -71,6 +71,28 @@ def test_default_spawn_and_reset_semantics():
         mrsgym_amd.make('mrs-v0', N_AGENTS=64, state_fn=state_fn)
 
 
+def test_user_spawn_distribution_and_start_ori():
+    """START_POS as a torch distribution (gen_data.py:30-36 style) and per-agent START_ORI ranges."""
+    import mrsgym_amd
+    from torch.distributions import Normal, Uniform
+    from mrsgym_amd.util import CombinedDistribution
+    N = 12
+    z = Uniform(low=2.0 * torch.ones(N, 1), high=5.0 * torch.ones(N, 1))
+    xy = Normal(torch.zeros(N, 2), 1.25)
+    joint = CombinedDistribution([xy, z], mixer='cat', dim=1)                   # (N,3) joint samples
+    single = CombinedDistribution([Normal(torch.zeros(2), 1.25), Uniform(2.0 * torch.ones(1), 5.0 * torch.ones(1))],
+                                  mixer='cat', dim=0)                            # (3,) per-agent samples
+    for dist_, E in ((joint, 1), (single, 1), (joint, 3)):
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, START_POS=dist_,
+                              START_ORI=torch.tensor([0., 0., -1., 0., 0., 1.]))
+        X = env.reset()
+        p = (X if E > 1 else X.unsqueeze(0))[:, 0, :, :3].cpu().numpy()
+        d = np.linalg.norm(p[:, :, None] - p[:, None], axis=-1) + np.eye(N) * 1e9
+        assert d.min() >= 0.6 - 1e-6 and (p[..., 2] >= 2).all() and (p[..., 2] <= 5).all()
+        yaw = env.get_env().get_ori()[..., 2].abs().max()
+        assert float(yaw) <= 1.0 + 1e-6
+
+
 def test_callbacks_and_quirks():
     import mrsgym_amd
     N = 5
