@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -91,16 +92,69 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *t
     }
 }
 
+
+// COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
+// the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
+template <int BLOCK>
+__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, size_t a, float4 mine)
+{
+    const bool n64 = (BLOCK == 256) && (A.N == 64);
+    if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
+    else lds_tile[tid] = mine;
+    __syncthreads();
+    if (n64) {
+        // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
+        // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
+        // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
+        // it is relative bit 64-k; k = 32 is tested by both ends.  All shifts are immediates on 32-bit
+        // halves; one 64-bit rotate by the lane index at the end turns relative into absolute columns.
+        if (live) {
+            const int lane = tid & 63;
+            const float4 *nb = lds_tile + el * 128 + lane;
+            const int lane4 = lane << 2;
+            uint32_t lo = 0, hi = 0; // relative bits 1..31 in lo, 32..63 in hi
+#pragma unroll
+            for (int k = 1; k <= 32; ++k) {
+                const float4 pj = nb[k];
+                const float dx = f32sub(mine.x, pj.x), dy = f32sub(mine.y, pj.y), dz = f32sub(mine.z, pj.z);
+                const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
+                const uint32_t close = A.comm_inf ? 1u : (uint32_t)(d2 <= A.d2_thresh);
+                if (k < 32) {
+                    lo |= close << k;
+                    hi |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)close) << (32 - k);
+                } else {
+                    hi |= close; // relative bit 32
+                }
+            }
+            const uint64_t rel = ((uint64_t)hi << 32) | lo;
+            A.b.adj[a] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+        }
+    } else if (live) {
+        adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+    }
+}
+
 // ------------------------------------------------------------------------------------ step kernel
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
 #endif
-template <int ACT, int BLOCK>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_step(const StepArgs A)
+#ifndef MRS_FUSED_WAVES
+// the fused kernels are held to 128 VGPRs = 4 resident waves per SIMD = all 1024 workgroups of the bench swarm
+// resident at once (set_target_vel / _pos would take 132 / 134 uncapped and drop to 3: measured 43.2 vs 37.5 us)
+#define MRS_FUSED_WAVES 4
+#endif
+// FUSED = true (256-thread workgroups): the whole of MRS.step in ONE launch -- the workgroup resolves its own
+// grounded bodies (compacted through LDS onto its first waves), then integrates poses and emits the newest
+// observation slice and adjacency rows from registers.  A dependent launch costs ~3 us on this stack and the
+// three-launch form pays it three times (measured: tools/micro/launch_floor.hip).
+// FUSED = false: velocities only; grounded bodies are queued for k_contact, observation/adjacency follow in
+// k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
+template <int ACT, int BLOCK, bool FUSED>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
 {
-    extern __shared__ float4 lds_tile[]; // BLOCK positions, then one int flag per env slot
+    extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
-    int *ncontact = nanflag + 256; // bodies of this workgroup queued for k_contact
+    int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
     const bool n64 = (BLOCK == 256) && (A.N == 64);
@@ -143,6 +197,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
     if (live && i == 0 && ACT != MRS_ACT_NONE && nanflag[el] && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
     int my_slot = -1;
+    bool parked = false;
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
         // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane.
@@ -311,7 +366,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             fb.z += downwash_acc;
         }
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
-        if (needs_contact(A.P, p[2])) {
+        if (FUSED) {
+            parked = needs_contact(A.P, p[2]);
+        } else if (needs_contact(A.P, p[2])) {
             // near the ground: queue the body for k_contact (compacted: the solver's cost scales with the
             // number of grounded bodies, and its registers stay out of this kernel).  Its pre-step pose and
             // unconstrained velocities travel in the slot-indexed planes of contact_state, so k_contact
@@ -321,6 +378,45 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? MRS_MIN_WAVES : 1)) void k_s
             integrate_pose(A.P, p, q, v, w);
             store_state(A.b, a, T, p, q, v, w);
         }
+    }
+    if (FUSED) {
+        // ---- contact: every lane stashes its state in LDS planes; the grounded bodies' lane ids are compacted
+        // into clist and solved by the first ceil(n/64) waves reading/writing those planes.  Nothing but the
+        // stash is live across the solve, so its registers and the controller's never coexist.
+        int *clist = ncontact + 2;
+        double *sp = reinterpret_cast<double *>(clist + BLOCK); // [13][BLOCK]
+        sp[tid] = p[0]; sp[BLOCK + tid] = p[1]; sp[2 * BLOCK + tid] = p[2];
+        sp[3 * BLOCK + tid] = q[0]; sp[4 * BLOCK + tid] = q[1]; sp[5 * BLOCK + tid] = q[2]; sp[6 * BLOCK + tid] = q[3];
+        sp[7 * BLOCK + tid] = v[0]; sp[8 * BLOCK + tid] = v[1]; sp[9 * BLOCK + tid] = v[2];
+        sp[10 * BLOCK + tid] = w[0]; sp[11 * BLOCK + tid] = w[1]; sp[12 * BLOCK + tid] = w[2];
+        if (parked) clist[atomicAdd(ncontact, 1)] = tid;
+        __syncthreads();
+        const int n = *ncontact; // uniform over the workgroup
+        if (n > 0) {
+            for (int sl = tid; sl < n; sl += BLOCK) {
+                const int b = clist[sl];
+                const double pp[3] = {0., 0., sp[2 * BLOCK + b]};
+                const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
+                double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
+                double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
+                contact_stage(A.P, pp, qq, vv, ww);
+                sp[7 * BLOCK + b] = vv[0]; sp[8 * BLOCK + b] = vv[1]; sp[9 * BLOCK + b] = vv[2];
+                sp[10 * BLOCK + b] = ww[0]; sp[11 * BLOCK + b] = ww[1]; sp[12 * BLOCK + b] = ww[2];
+            }
+            __syncthreads();
+        }
+        p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
+        q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
+        v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
+        w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
+        if (doit) {
+            integrate_pose(A.P, p, q, v, w);
+            store_state(A.b, a, T, p, q, v, w);
+        }
+        // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
+        if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
+        if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, a, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        return;
     }
     // Two-level compaction into one global list: lanes take slots from an LDS counter, ONE lane per
     // workgroup reserves the range with a single device-scope atomic (a per-wave atomic on one word
@@ -391,43 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
         if (nw) { w[0] = A.b.angvel[a]; w[1] = A.b.angvel[T + a]; w[2] = A.b.angvel[2 * T + a]; }
     }
     if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
-    if (A.do_adj) {
-        const bool n64 = (BLOCK == 256) && (A.N == 64);
-        const float4 mine = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
-        if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
-        else lds_tile[tid] = mine;
-        __syncthreads();
-        if (n64) {
-            // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
-            // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
-            // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
-            // it is relative bit 64-k; k = 32 is tested by both ends.  All shifts are immediates on 32-bit
-            // halves; one 64-bit rotate by the lane index at the end turns relative into absolute columns.
-            if (live) {
-                const int lane = tid & 63;
-                const float4 *nb = lds_tile + el * 128 + lane;
-                const int lane4 = lane << 2;
-                uint32_t lo = 0, hi = 0; // relative bits 1..31 in lo, 32..63 in hi
-#pragma unroll
-                for (int k = 1; k <= 32; ++k) {
-                    const float4 pj = nb[k];
-                    const float dx = f32sub(mine.x, pj.x), dy = f32sub(mine.y, pj.y), dz = f32sub(mine.z, pj.z);
-                    const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
-                    const uint32_t close = A.comm_inf ? 1u : (uint32_t)(d2 <= A.d2_thresh);
-                    if (k < 32) {
-                        lo |= close << k;
-                        hi |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)close) << (32 - k);
-                    } else {
-                        hi |= close; // relative bit 32
-                    }
-                }
-                const uint64_t rel = ((uint64_t)hi << 32) | lo;
-                A.b.adj[a] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
-            }
-        } else if (live) {
-            adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
-        }
-    }
+    if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, a, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
 }
 
 // packed (M,N,W) -> dense float32 (M,N,N), one thread per output element (coalesced along j)
@@ -616,6 +676,7 @@ struct MrsHandle {
     double hclip;
     int *ws;            // device workspace: [0..1] two alternating contact counters, [2..2+T) contact list
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
+    bool fused;         // one-launch step (256-thread workgroups; MRS_STEP_SPLIT=1 keeps the three-launch form)
     unsigned step_parity;
 };
 
@@ -719,6 +780,8 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     if (n_agents <= 256) { h->block = 256; h->epb = 256 / n_agents; }
     else { h->block = 1024; h->epb = 1; }
     h->W = (n_agents + 63) / 64;
+    const char *split = getenv("MRS_STEP_SPLIT");
+    h->fused = (h->block == 256) && !(split && split[0] == '1');
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
@@ -786,12 +849,14 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
 static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st);
 
 template <int ACT>
-static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st)
+static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, bool fused)
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
     const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
-    if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256>), dim3(grid), dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((k_step<ACT, 1024>), dim3(grid), dim3(1024), lds, st, A);
+    // fused: + compacted lane list + 13 float64 state planes (36 872 B; 4 workgroups per CU fit the 160 KB LDS)
+    if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double), st, A);
+    else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, A);
     return hipGetLastError();
 }
 
@@ -817,16 +882,18 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     h->step_parity++;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
+    const bool fused = h->fused;
     switch (action_type) {
-    case MRS_ACT_NONE: e = launch_step<MRS_ACT_NONE>(h, A, st); break;
-    case MRS_ACT_SET_SPEEDS: e = launch_step<MRS_ACT_SET_SPEEDS>(h, A, st); break;
-    case MRS_ACT_SET_CONTROL: e = launch_step<MRS_ACT_SET_CONTROL>(h, A, st); break;
-    case MRS_ACT_TARGET_ACCEL: e = launch_step<MRS_ACT_TARGET_ACCEL>(h, A, st); break;
-    case MRS_ACT_TARGET_VEL: e = launch_step<MRS_ACT_TARGET_VEL>(h, A, st); break;
-    case MRS_ACT_TARGET_POS: e = launch_step<MRS_ACT_TARGET_POS>(h, A, st); break;
-    default: e = launch_step<MRS_ACT_TARGET_ORI>(h, A, st); break;
+    case MRS_ACT_NONE: e = launch_step<MRS_ACT_NONE>(h, A, st, fused); break;
+    case MRS_ACT_SET_SPEEDS: e = launch_step<MRS_ACT_SET_SPEEDS>(h, A, st, fused); break;
+    case MRS_ACT_SET_CONTROL: e = launch_step<MRS_ACT_SET_CONTROL>(h, A, st, fused); break;
+    case MRS_ACT_TARGET_ACCEL: e = launch_step<MRS_ACT_TARGET_ACCEL>(h, A, st, fused); break;
+    case MRS_ACT_TARGET_VEL: e = launch_step<MRS_ACT_TARGET_VEL>(h, A, st, fused); break;
+    case MRS_ACT_TARGET_POS: e = launch_step<MRS_ACT_TARGET_POS>(h, A, st, fused); break;
+    default: e = launch_step<MRS_ACT_TARGET_ORI>(h, A, st, fused); break;
     }
     if (e != hipSuccess) return hipfail(e, "mrs_step launch");
+    if (fused) return 0;
     if (h->P.enable_contact) {
         // worst-case grid; blocks beyond the device-side count return at once
         const int T = h->E * h->N;
