@@ -612,6 +612,9 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
 #ifndef MRS_CONTACT_F32
 #define MRS_CONTACT_F32 1
 #endif
+#ifndef MRS_CONTACT_TOL
+#define MRS_CONTACT_TOL 1e-7f
+#endif
 struct F3 {
     float x, y, z;
 };
@@ -633,21 +636,29 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
              cz = {(float)(sgn * hl * R.m02), (float)(sgn * hl * R.m12), (float)czz};
     unsigned active = 0;
     float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
+    // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows
+    F3 r[4], an[4], ax[4], ay[4];
     const double rdt = 1.0 / P.dt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ln[k] = lx[k] = ly[k] = Kn[k] = Kx[k] = Ky[k] = rhs[k] = 0.f;
+        r[k] = an[k] = ax[k] = ay[k] = F3{0.f, 0.f, 0.f};
         const double rzd = ((k & 1) ? -cxz : cxz) + ((k & 2) ? -cyz : cyz) + czz;
         const double dist = pz + rzd - P.ground_z;
         if (!(dist <= P.contact_threshold)) continue;
         active |= 1u << k;
         const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
         const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
-        const float rz = (float)rzd;
-        // u^T Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
+        const float rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + cz.z;
+        r[k] = F3{rx, ry, rz};
+        // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
+        an[k] = F3{Ixx * ry - Ixy * rx, Ixy * ry - Iyy * rx, Ixz * ry - Iyz * rx};
+        ax[k] = F3{Ixy * rz - Ixz * ry, Iyy * rz - Iyz * ry, Iyz * rz - Izz * ry};
+        ay[k] = F3{-Ixx * rz + Ixz * rx, -Ixy * rz + Iyz * rx, -Ixz * rz + Izz * rx};
+        const float rzs = (float)rzd; // lever z for the effective masses, rounded once from float64 (as the oracle's gap)
         Kn[k] = __builtin_amdgcn_rcpf(im + (ry * (Ixx * ry - Ixy * rx) - rx * (Ixy * ry - Iyy * rx)));
-        Kx[k] = __builtin_amdgcn_rcpf(im + (rz * (Iyy * rz - Iyz * ry) - ry * (Iyz * rz - Izz * ry)));
-        Ky[k] = __builtin_amdgcn_rcpf(im + (-rz * (-Ixx * rz + Ixz * rx) + rx * (-Ixz * rz + Izz * rx)));
+        Kx[k] = __builtin_amdgcn_rcpf(im + (rzs * (Iyy * rzs - Iyz * ry) - ry * (Iyz * rzs - Izz * ry)));
+        Ky[k] = __builtin_amdgcn_rcpf(im + (-rzs * (-Ixx * rzs + Ixz * rx) + rx * (-Ixz * rzs + Izz * rx)));
         const double vrel0 = v.z + (w.x * (double)ry - w.y * (double)rx);
         double poserr = 0., velerr = -vrel0;
         if (dist > 0) velerr -= dist * rdt; else poserr = -dist * P.erp * rdt;
@@ -660,15 +671,13 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
     // the sweeps gain ~1.5 digits each (measured on the oracle); a lane stops once a whole sweep moved no
     // impulse by more than 1e-7 of the resting impulse m g dt -- float32 cannot resolve less anyway --
     // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle)
-    const float tol = 1e-7f * (float)(P.mass * P.gravity * P.dt) + 1e-30f;
+    const float tol = MRS_CONTACT_TOL * (float)(P.mass * P.gravity * P.dt) + 1e-30f;
     for (int it = 0; it < P.solver_iters; ++it) {
         float moved = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!(active & (1u << k))) continue;
-            const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
-            const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
-            const float rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + cz.z;
+            const float rx = r[k].x, ry = r[k].y, rz = r[k].z;
             { // normal: u = (ry, -rx, 0)
                 const float dvn = dvz + (dwx * ry - dwy * rx);
                 float nl = ln[k] + Kn[k] * (rhs[k] - dvn);
@@ -677,7 +686,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
                 ln[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
                 dvz += dl * im;
-                dwx += (Ixx * ry - Ixy * rx) * dl; dwy += (Ixy * ry - Iyy * rx) * dl; dwz += (Ixz * ry - Iyz * rx) * dl;
+                dwx += an[k].x * dl; dwy += an[k].y * dl; dwz += an[k].z * dl;
             }
             const float lim = mu * ln[k];
             { // friction x: u = (0, rz, -ry)
@@ -688,7 +697,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
                 lx[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
                 dvx += dl * im;
-                dwx += (Ixy * rz - Ixz * ry) * dl; dwy += (Iyy * rz - Iyz * ry) * dl; dwz += (Iyz * rz - Izz * ry) * dl;
+                dwx += ax[k].x * dl; dwy += ax[k].y * dl; dwz += ax[k].z * dl;
             }
             { // friction y: u = (-rz, 0, rx)
                 const float vt = (v0y + dvy) + ((w0z + dwz) * rx - (w0x + dwx) * rz);
@@ -698,7 +707,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
                 ly[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
                 dvy += dl * im;
-                dwx += (-Ixx * rz + Ixz * rx) * dl; dwy += (-Ixy * rz + Iyz * rx) * dl; dwz += (-Ixz * rz + Izz * rx) * dl;
+                dwx += ay[k].x * dl; dwy += ay[k].y * dl; dwz += ay[k].z * dl;
             }
         }
         if (moved <= tol) break;
