@@ -97,18 +97,34 @@ MRS_DEV double rsqrt64(double x)
 // libm routines (Payne-Hanek reduction, special-value branches) are dead weight per lane.  These use
 // a two-term Cody-Waite reduction by at most +-2 quadrants and the classic fdlibm minimax kernels
 // (< 1 ulp on |r| <= pi/4); arguments outside +-4 fall back to the library.
+// Horner steps p <- a*b + C with the float64 coefficient C as an SGPR-pair operand of a VOP3 v_fma_f64.
+// Left to itself the compiler selects the two-address v_fmac_f64, whose addend must sit in the destination
+// VGPR pair: two v_mov_b32 per coefficient per use, ~600 of the step kernel's ~3000 vector instructions with
+// the polynomials inlined at ~20 sites.  The "s" constraint makes it build C with two s_mov_b32 instead
+// (scalar unit, off the VALU port the kernel is bound by).
+MRS_DEV double fma_c(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
 MRS_DEV double ksin(double r)
 {
     const double z = r * r;
-    const double p = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
-                     z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    return r + (r * z) * (-1.66666666666666324348e-01 + z * p);
+    double p = z * 1.58969099521155010221e-10 + -2.50507602534068634195e-08;
+    p = fma_c(p, z, 2.75573137070700676789e-06);
+    p = fma_c(p, z, -1.98412698298579493134e-04);
+    p = fma_c(p, z, 8.33333333332248946124e-03);
+    return r + (r * z) * fma_c(p, z, -1.66666666666666324348e-01);
 }
 MRS_DEV double kcos(double r)
 {
     const double z = r * r;
-    const double p = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                     z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    double p = z * -1.13596475577881948265e-11 + 2.08757232129817482790e-09;
+    p = fma_c(p, z, -2.75573143513906633035e-07);
+    p = fma_c(p, z, 2.48015872894767294178e-05);
+    p = fma_c(p, z, -1.38888888888741095749e-03);
+    p = fma_c(p, z, 4.16666666666666019037e-02);
     return (1.0 - 0.5 * z) + (z * z) * p;
 }
 MRS_DEV void fast_sincos(double x, double *s, double *c)
@@ -127,11 +143,16 @@ MRS_DEV void fast_sincos(double x, double *s, double *c)
 MRS_DEV double katan(double t)
 {
     const double z = t * t, w = z * z;
-    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
-                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
-                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
-    return t - t * (s1 + s2);
+    double e = w * 1.62858201153657823623e-02 + 4.97687799461593236017e-02;
+    e = fma_c(e, w, 6.66107313738753120669e-02);
+    e = fma_c(e, w, 9.09088713343650656196e-02);
+    e = fma_c(e, w, 1.42857142725034663711e-01);
+    e = fma_c(e, w, 3.33333333333329318027e-01);
+    double o = w * -3.65315727442169155270e-02 + -5.83357013379057348645e-02;
+    o = fma_c(o, w, -7.69187620504482999495e-02);
+    o = fma_c(o, w, -1.11111104054623557880e-01);
+    o = fma_c(o, w, -1.99999999998764832476e-01);
+    return t - t * (z * e + w * o);
 }
 MRS_DEV double fast_atan2(double y, double x)
 {
@@ -246,7 +267,7 @@ MRS_DEV void observe(const double p[3], const double q[4], const double v[3], co
 // Reciprocals of per-launch constants, computed once on the host (a wave-uniform float64 division would
 // otherwise still cost every lane its ~12-instruction division sequence).
 struct Recips {
-    double inv_mass, inv_i0, inv_i1, inv_i2, inv_4kf;
+    double inv_mass, inv_i0, inv_i1, inv_i2, inv_4kf, inv_dt; // host-computed: a float64 division is ~14 VALU per lane
 };
 
 // Controller memory of one quadcopter, in registers for the duration of a step.
@@ -618,11 +639,11 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
 struct F3 {
     float x, y, z;
 };
-MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v, V3 &w)
+MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, V3 &v, V3 &w)
 {
     const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
-    const float i0 = (float)(1.0 / P.inertia[0]), i1 = (float)(1.0 / P.inertia[1]), i2 = (float)(1.0 / P.inertia[2]);
-    const float im = (float)(1.0 / P.mass);
+    const float i0 = (float)K.inv_i0, i1 = (float)K.inv_i1, i2 = (float)K.inv_i2;
+    const float im = (float)K.inv_mass;
     const float r00 = (float)R.m00, r01 = (float)R.m01, r02 = (float)R.m02, r10 = (float)R.m10, r11 = (float)R.m11,
                 r12 = (float)R.m12, r20 = (float)R.m20, r21 = (float)R.m21, r22 = (float)R.m22;
     const float Ixx = r00 * r00 * i0 + r01 * r01 * i1 + r02 * r02 * i2, Ixy = r00 * r10 * i0 + r01 * r11 * i1 + r02 * r12 * i2,
@@ -638,7 +659,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
     float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
     // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows
     F3 r[4], an[4], ax[4], ay[4];
-    const double rdt = 1.0 / P.dt;
+    const double rdt = K.inv_dt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ln[k] = lx[k] = ly[k] = Kn[k] = Kx[k] = Ky[k] = rhs[k] = 0.f;
@@ -716,12 +737,12 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, double pz, const M3 &R, V3 &v
     w.x += (double)dwx; w.y += (double)dwy; w.z += (double)dwz;
 }
 
-MRS_DEV void contact_stage(const MrsParams &P, const double p[3], const double q[4], double v[3], double w[3])
+MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
 {
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
     V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
 #if MRS_CONTACT_F32
-    contact_solve_f32(P, p[2], R, vv, ww);
+    contact_solve_f32(P, K, p[2], R, vv, ww);
 #else
     contact_solve(P, p[2], R, vv, ww);
 #endif
