@@ -51,10 +51,43 @@ __device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_
     b.angvel[a] = w[0]; b.angvel[T + a] = w[1]; b.angvel[2 * T + a] = w[2];
 }
 
-// newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
-__device__ __forceinline__ void write_obs(const StepArgs &A, size_t a, const double p[3], const double q[4], const double v[3], const double w[3])
+// Workgroup-relative addressing.  Agent a = wg_base + tid for every live lane of k_step / k_observe_adj, so a
+// plane access is (uniform pointer, SGPR pair) + (small 32-bit per-lane offset): the saddr form of global_load /
+// global_store, with the plane arithmetic on the scalar unit -- instead of one 64-bit VALU add per lane for
+// each of the ~70 plane accesses of a step.
+struct WgBuffers {
+    double *pos, *quat, *vel, *angvel;
+    float *pid, *obs, *rpm;
+    uint64_t *adj;
+};
+__device__ __forceinline__ WgBuffers wg_buffers(const StepArgs &A, size_t wg_base)
 {
-    float *o = A.b.obs + a * (size_t)A.D;
+    WgBuffers w;
+    w.pos = A.b.pos + wg_base; w.quat = A.b.quat + wg_base; w.vel = A.b.vel + wg_base; w.angvel = A.b.angvel + wg_base;
+    w.pid = A.b.pid ? A.b.pid + wg_base : nullptr;
+    w.rpm = A.b.rpm ? A.b.rpm + wg_base : nullptr;
+    w.obs = A.b.obs ? A.b.obs + wg_base * (size_t)A.D : nullptr;
+    w.adj = A.b.adj ? A.b.adj + wg_base * (size_t)A.W : nullptr;
+    return w;
+}
+__device__ __forceinline__ void load_state(const WgBuffers &b, unsigned t, size_t T, double p[3], double q[4], double v[3], double w[3])
+{
+    p[0] = b.pos[t]; p[1] = (b.pos + T)[t]; p[2] = (b.pos + 2 * T)[t];
+    q[0] = b.quat[t]; q[1] = (b.quat + T)[t]; q[2] = (b.quat + 2 * T)[t]; q[3] = (b.quat + 3 * T)[t];
+    v[0] = b.vel[t]; v[1] = (b.vel + T)[t]; v[2] = (b.vel + 2 * T)[t];
+    w[0] = b.angvel[t]; w[1] = (b.angvel + T)[t]; w[2] = (b.angvel + 2 * T)[t];
+}
+__device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size_t T, const double p[3], const double q[4], const double v[3], const double w[3])
+{
+    b.pos[t] = p[0]; (b.pos + T)[t] = p[1]; (b.pos + 2 * T)[t] = p[2];
+    b.quat[t] = q[0]; (b.quat + T)[t] = q[1]; (b.quat + 2 * T)[t] = q[2]; (b.quat + 3 * T)[t] = q[3];
+    b.vel[t] = v[0]; (b.vel + T)[t] = v[1]; (b.vel + 2 * T)[t] = v[2];
+    b.angvel[t] = w[0]; (b.angvel + T)[t] = w[1]; (b.angvel + 2 * T)[t] = w[2];
+}
+
+// newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
+__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
+{
     bool want_euler = false;
     for (int f = 0; f < A.n_obs; ++f) want_euler |= (A.obs_fields[f] == MRS_OBS_EULER);
     Observed ob;
@@ -96,7 +129,7 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *t
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 template <int BLOCK>
-__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, size_t a, float4 mine)
+__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, uint64_t *row, float4 mine)
 {
     const bool n64 = (BLOCK == 256) && (A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
@@ -127,10 +160,10 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
                 }
             }
             const uint64_t rel = ((uint64_t)hi << 32) | lo;
-            A.b.adj[a] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+            row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
         }
     } else if (live) {
-        adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], A.b.adj + a * (size_t)A.W);
+        adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], row);
     }
 }
 
@@ -166,6 +199,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool live = (el < A.epb) && (e < A.E);
     const size_t T = (size_t)A.T;
     const size_t a = live ? (size_t)e * A.N + i : 0;
+    const unsigned la = live ? (unsigned)tid : 0u;                                        // a == wg_base + la
+    const WgBuffers wb = wg_buffers(A, (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N);
     constexpr int ADIM = (ACT == MRS_ACT_SET_SPEEDS || ACT == MRS_ACT_SET_CONTROL) ? 4 : 3;
 
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
@@ -173,10 +208,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (tid < A.epb) nanflag[tid] = 0;
     if (tid == 0) *ncontact = 0;
     if (live) {
-        load_state(A.b, a, T, p, q, v, w);
+        load_state(wb, la, T, p, q, v, w);
         if (ACT != MRS_ACT_NONE) {
+            const float *ap = A.actions + (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N * ADIM;
 #pragma unroll
-            for (int k = 0; k < ADIM; ++k) act[k] = A.actions[a * ADIM + k];
+            for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
         }
     }
     if (n64) {
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             if (ACT == MRS_ACT_TARGET_VEL || ACT == MRS_ACT_TARGET_POS) {
                 Observed o0;
                 observe<false, false>(p, q, v, w, o0);
-                float *g = A.b.pid + a;
+                float *g = wb.pid + la;
                 if (ACT == MRS_ACT_TARGET_POS) {
                     s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T];
                     ta = pos_control_accel(P, s, o0, act[0], act[1], act[2]);
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             Observed ob;
             observe<true, true>(p, q, v, w, ob);
             if (NEEDS_PID) {
-                float *g = A.b.pid + a;
+                float *g = wb.pid + la;
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
                 const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
@@ -304,7 +340,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
             if (A.b.rpm) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) A.b.rpm[k * T + a] = (float)rpm[k];
+                for (int k = 0; k < 4; ++k) (wb.rpm + k * T)[la] = (float)rpm[k];
             }
             // ---- Quadcopter.set_speeds (Quadcopter.py:38-45): rotor thrusts + yaw reaction torque.
             // With ACTION_TYPE=set_speeds the reference's arithmetic is float32 (float32 action tensor).
@@ -377,7 +413,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             my_slot = atomicAdd(ncontact, 1); // LDS counter: slot inside this workgroup's reservation
         } else {
             integrate_pose(A.P, p, q, v, w);
-            store_state(A.b, a, T, p, q, v, w);
+            store_state(wb, la, T, p, q, v, w);
         }
     }
     if (FUSED) {
@@ -412,11 +448,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
         if (doit) {
             integrate_pose(A.P, p, q, v, w);
-            store_state(A.b, a, T, p, q, v, w);
+            store_state(wb, la, T, p, q, v, w);
         }
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
-        if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
-        if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, a, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+        if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
         return;
     }
     // Two-level compaction into one global list: lanes take slots from an LDS counter, ONE lane per
@@ -472,7 +508,8 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
     const int i = tid - el * A.N;
     const int e = blockIdx.x * A.epb + el;
     const bool live = (el < A.epb) && (e < A.E);
-    const size_t a = live ? (size_t)e * A.N + i : 0;
+    const unsigned la = live ? (unsigned)tid : 0u;
+    const WgBuffers wb = wg_buffers(A, (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N);
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
     if (live) { // only the planes the observation spec names are moved (cat(pos, vel): 48 of the 104 bytes)
         const size_t T = (size_t)A.T;
@@ -482,13 +519,13 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
             nv |= (A.obs_fields[f] == MRS_OBS_VEL);
             nw |= (A.obs_fields[f] == MRS_OBS_ANGVEL);
         }
-        p[0] = A.b.pos[a]; p[1] = A.b.pos[T + a]; p[2] = A.b.pos[2 * T + a];
-        if (nq) { q[0] = A.b.quat[a]; q[1] = A.b.quat[T + a]; q[2] = A.b.quat[2 * T + a]; q[3] = A.b.quat[3 * T + a]; }
-        if (nv) { v[0] = A.b.vel[a]; v[1] = A.b.vel[T + a]; v[2] = A.b.vel[2 * T + a]; }
-        if (nw) { w[0] = A.b.angvel[a]; w[1] = A.b.angvel[T + a]; w[2] = A.b.angvel[2 * T + a]; }
+        p[0] = wb.pos[la]; p[1] = (wb.pos + T)[la]; p[2] = (wb.pos + 2 * T)[la];
+        if (nq) { q[0] = wb.quat[la]; q[1] = (wb.quat + T)[la]; q[2] = (wb.quat + 2 * T)[la]; q[3] = (wb.quat + 3 * T)[la]; }
+        if (nv) { v[0] = wb.vel[la]; v[1] = (wb.vel + T)[la]; v[2] = (wb.vel + 2 * T)[la]; }
+        if (nw) { w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la]; }
     }
-    if (A.b.obs && live && A.n_obs > 0) write_obs(A, a, p, q, v, w);
-    if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, a, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+    if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+    if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
 }
 
 // packed (M,N,W) -> dense float32 (M,N,N), one thread per output element (coalesced along j)
