@@ -702,7 +702,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
             { // normal: u = (ry, -rx, 0)
                 const float dvn = dvz + (dwx * ry - dwy * rx);
                 float nl = ln[k] + Kn[k] * (rhs[k] - dvn);
-                nl = nl < 0.f ? 0.f : nl;
+                nl = fmaxf(nl, 0.f);                          // v_max_f32 (a compare + select pair otherwise)
                 const float dl = nl - ln[k];
                 ln[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
@@ -713,7 +713,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
             { // friction x: u = (0, rz, -ry)
                 const float vt = (v0x + dvx) + ((w0y + dwy) * rz - (w0z + dwz) * ry);
                 float nl = lx[k] - Kx[k] * vt;
-                nl = nl < -lim ? -lim : (nl > lim ? lim : nl);
+                nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);  // friction pyramid clamp in one v_med3_f32
                 const float dl = nl - lx[k];
                 lx[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
@@ -723,7 +723,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
             { // friction y: u = (-rz, 0, rx)
                 const float vt = (v0y + dvy) + ((w0z + dwz) * rx - (w0x + dwx) * rz);
                 float nl = ly[k] - Ky[k] * vt;
-                nl = nl < -lim ? -lim : (nl > lim ? lim : nl);
+                nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);  // friction pyramid clamp in one v_med3_f32
                 const float dl = nl - ly[k];
                 ly[k] = nl;
                 moved = fmaxf(moved, fabsf(dl));
