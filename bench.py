@@ -10,8 +10,9 @@ cat(pos, vel); synthetic swarm of SURVEY.md 8d (grid spawn, per-agent U[-1,1]^3 
 steps, pre-generated on the device).  One "step" = one env.step(actions) of the product API over the
 whole batch: fused controller + rotor/aero forces + downwash + 6-DoF integration + ground contact +
 newest observation slice + bit-packed newest adjacency rows, written into the K_HOPS history ring.
-Weak scaling: every GPU owns 4096 envs; with N>1 the newest observation slice is all-gathered over
-RCCL each step (side stream, overlapped).
+Weak scaling: every GPU owns 4096 envs and step() has no exchange between them, so `value` times the
+sharded path alone; with N>1 the same K steps are then repeated with the joint observation tensor
+all-gathered over RCCL every step (side stream, double-buffered) and reported as `with_obs_allgather`.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM (algorithmic bytes,
 SURVEY.md 8d: 268 B per agent-step at this config); `cpu_baseline` times the CPU oracle (a C port of
@@ -109,7 +110,7 @@ def main():
 
     acts = ActionStream(ATYPE, E, N, pos, seed=1000 + rank)
     total = args.warmup + args.steps
-    table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range(total // 50 + 1)]
+    table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range((2 * total if world > 1 else total) // 50 + 1)]
     # Process/device warm-up on a SCRATCH swarm, before the W warm-up steps of the measured one: the first
     # ~0.1 s of launches of a fresh process run ~20 % slow (62 vs 52 us/step measured; clock ramp + the HIP
     # runtime growing its signal/kernarg pools), and on a fresh box the first process is slower still.  The
@@ -127,57 +128,75 @@ def main():
     assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
     gather = mdist.ObsAllGather(E, N, 6, dev) if world > 1 else None
 
-    def one_step(t):
-        X, r, d, info = env.step(table[t // 50])
-        if gather is not None:
+    def one_step(t, with_gather):
+        X, r, d, info = env.step(table[(t // 50) % len(table)])
+        if with_gather:
             gather.gather(env._Xring.newest())
         return X, info
 
-    for t in range(args.warmup):
-        one_step(t)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
     # HIP events on the stream the step kernels are launched on (torch's current stream) bracket SPANS of
     # EV_SPAN consecutive mrs_step launches, one span every EV_EVERY steps: on this stack a timing-event pair
     # costs the stream ~60 us (measured 137 us per step with a pair on every step against 76 us with none),
     # so the per-launch duration is sampled and the pair's cost amortised over the span.
     EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
     EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "10")), EV_EVERY, args.steps))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(max(1, (args.steps - EV_SPAN) // EV_EVERY + 1))]
     shard_step = env.shard.step_ptr
 
-    def timed_step(*a, **k):
-        i = timed_step.i
-        timed_step.i = i + 1
-        j, r = divmod(i, EV_EVERY)
-        if j < len(ev) and r == 0:
-            ev[j][0].record()
-        shard_step(*a, **k)
-        if j < len(ev) and r == EV_SPAN - 1:
-            ev[j][1].record()
-    timed_step.i = 0
-    env.shard.step_ptr = timed_step
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total):
-        one_step(t)
-    host_elapsed = time.perf_counter() - t0     # launch loop only: equals `elapsed` when the host is the limit
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    def timed_region(t_first, with_gather):
+        """W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier; max over ranks."""
+        for t in range(t_first, t_first + args.warmup):
+            one_step(t, with_gather)
+        if with_gather:
+            gather.wait()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    env.shard.step_ptr = shard_step
-    env.check_errors()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / EV_SPAN
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(max(1, (args.steps - EV_SPAN) // EV_EVERY + 1))]
+
+        def timed_step(*a, **k):
+            i = timed_step.i
+            timed_step.i = i + 1
+            j, r = divmod(i, EV_EVERY)
+            if j < len(ev) and r == 0:
+                ev[j][0].record()
+            shard_step(*a, **k)
+            if j < len(ev) and r == EV_SPAN - 1:
+                ev[j][1].record()
+        timed_step.i = 0
+        env.shard.step_ptr = timed_step
+        t0 = time.perf_counter()
+        for t in range(t_first + args.warmup, t_first + total):
+            one_step(t, with_gather)
+        host_elapsed = time.perf_counter() - t0     # launch loop only: equals `elapsed` when the host is the limit
+        if with_gather:
+            gather.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        env.shard.step_ptr = shard_step
+        env.check_errors()
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / EV_SPAN
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, host_elapsed, kernel_ms
+
+    # `value`: the sharded path itself -- envs are independent, so step() has no exchange and none is timed.
+    elapsed, host_elapsed, kernel_ms = timed_region(0, False)
+    # N > 1, reported beside it: the same K steps with the joint observation tensor all-gathered over RCCL every
+    # step (SURVEY.md 8e; side stream, double-buffered), for consumers that want every rank to hold all of X.
+    gathered = None
+    if world > 1 and os.environ.get("MRS_BENCH_OBS_ALLGATHER", "1") == "1":
+        g_elapsed, _, _ = timed_region(total, True)
+        gathered = {"value": float(E) * N * args.steps * world / g_elapsed, "unit": "agent-steps/s",
+                    "ms_per_step": g_elapsed / args.steps * 1e3,
+                    "bytes_sent_per_rank_per_step": E * N * 6 * 4 * (world - 1),
+                    "what": "newest observation slice (E_local,N,6) float32 all-gathered to every rank each step (RCCL)"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -188,7 +207,7 @@ def main():
     achieved = algo_bytes_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes (see profiles/README.md)
-    if os.path.exists(tp):
+    if os.path.exists(tp) and E == ENVS_PER_GPU and not args.dense_a:   # counters were collected on the default workload
         try:
             traffic = json.load(open(tp)).get("mrs_step_bytes_per_launch")
         except Exception:
@@ -201,11 +220,13 @@ def main():
         "config": {"workload": "N_AGENTS=64 x %d envs/GPU, ACTION_TYPE=set_target_vel (PID), RETURN_A=True COMM_RANGE=5.0, "
                                "K_HOPS=3, state_fn=cat(pos,vel), A %s" % (E, "dense fp32" if args.dense_a else "bit-packed"),
                    "n_agents": N, "n_envs_per_gpu": E, "k_hops": K_HOPS, "comm_range": COMM_RANGE,
-                   "parallelism": "env-sharded x%d, obs all-gather" % world if world > 1 else "single GPU"},
+                   "parallelism": "env-sharded x%d, no exchange inside step()" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": algo_bytes_launch},
     }
+    if gathered is not None:
+        out["with_obs_allgather"] = gathered
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
