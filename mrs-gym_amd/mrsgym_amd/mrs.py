@@ -77,6 +77,7 @@ class MRS(_EnvBase):
         self.CHECK_NAN = None         # "sync" | "lazy" | "off"; None = sync for N_ENVS==1 else lazy
         self.HISTORY_SLOTS = 0        # ring length; 0 = 8*(K_HOPS+1)
         self.COPY_OUTPUTS = None      # None = clone returned stacks iff N_ENVS == 1 (reference returns fresh tensors)
+        self.AUTO_RESET = False       # vectorised loops: envs whose `done` is set are reset inside step() (reset_envs)
         # BulletSim constants (BulletSim.py:11-15); DT/GRAVITY reach the world only, never the controller
         self.REAL_TIME = False
         self.GRAVITY = 9.81
@@ -124,6 +125,8 @@ class MRS(_EnvBase):
         self.last_loop_time = time.monotonic()
         self.is_initialised = False
         self._resets = 0
+        self._global_step = 0
+        self._reset_step = torch.zeros(self.N_ENVS, dtype=torch.int64, device=self.device)  # per env: _global_step at its last reset
         self._alloc_history()
         self.reset()
 
@@ -144,6 +147,9 @@ class MRS(_EnvBase):
     def _stack_view(self, w):
         """ring window (K+1, E, ...) -> the reference's stack layout (E, K+1, ...) / (K+1, ...) for one env."""
         return self._squeeze(w.permute(1, 0, 2, 3))
+
+    def _copies(self):
+        return self.COPY_OUTPUTS if self.COPY_OUTPUTS is not None else (self.N_ENVS == 1)
 
     def _out(self, t):
         # the reference returns fresh tensors every step; views into the history ring are overwritten
@@ -266,7 +272,7 @@ class MRS(_EnvBase):
         x = torch.rand(shape, device=self.device)
         return x * (hi - lo).to(self.device) + lo.to(self.device)
 
-    def _default_spawn(self):
+    def _default_spawn(self, env_mask=None):
         """START_POS=None: the reference's default_spawn_dist() + rejection, on the device (mrs_spawn)."""
         so = torch.as_tensor(self.START_ORI, dtype=torch.float32)
         if so.dim() == 2 and not bool((so == so[0]).all()):
@@ -279,7 +285,7 @@ class MRS(_EnvBase):
         self._resets += 1
         self.shard.status.zero_()
         self.shard.spawn(seed=(int(self.SEED) << 20) + self._resets, env_index_base=self.ENV_INDEX_BASE,
-                         agent_radius=self.AGENT_RADIUS, ori_lo=lo, ori_hi=hi)
+                         agent_radius=self.AGENT_RADIUS, ori_lo=lo, ori_hi=hi, env_mask=env_mask)
         if int((self.shard.status & native.STATUS_SPAWN_FAIL).any()):
             raise RuntimeError("default spawn: %d agents of radius %.2f do not fit the unit-disc x [1,3] m volume "
                                "(the reference's generate_start_pos never terminates here, MRS.py:137-153); "
@@ -313,11 +319,60 @@ class MRS(_EnvBase):
             self.shard.pid_reset()
         self._clear_history()
         self.steps_since_reset = 0
+        self._reset_step.fill_(self._global_step)
         if self.start_fn is not None:
             self.start_fn(self)
         Xk = self.calc_Xk()
         self.last_obs = Xk
         return Xk
+
+    def reset_envs(self, env_mask, pos=None, ori=None, vel=None, angvel=None):
+        """reset() for the envs selected by `env_mask` (bool, (E,)) only -- the vectorised counterpart of calling
+        MRS.reset (MRS.py:174-192) on some of E independent reference instances.  The other envs keep their state,
+        controller memory and K_HOPS history.  Selected envs: new start state (same START_POS / START_ORI rules),
+        zero velocities, X history = K+1 copies of the new observation (MRS.py:92-93), A history = zeros
+        (MRS.py:107-108; like reset(), no adjacency is computed until the next step).  State, controller memory and
+        history are written through env masks on the device.  Returns the stacked Xk of all envs."""
+        if not self.is_initialised:
+            raise RuntimeError("reset_envs() before reset()")
+        E, N = self.N_ENVS, self.N_AGENTS
+        mask = torch.as_tensor(env_mask, device=self.device).to(torch.bool).reshape(E)
+        spawned = False
+        if pos is None and self.START_POS is None:
+            spawned = self._default_spawn(env_mask=mask)
+            if not spawned:
+                saved, self.START_POS = self.START_POS, self.default_spawn_dist()
+                pos = self.generate_start_pos()
+                self.START_POS = saved
+        elif pos is None:
+            pos = self.generate_start_pos()
+        if ori is None and not spawned:
+            ori = self.generate_start_ori()
+            if ori.dim() == 2 and E > 1:
+                ori = ori.unsqueeze(0).expand(E, N, ori.shape[-1])
+        if not spawned:
+            self.shard.set_state(pos=pos, ori=ori, vel=torch.zeros(E, N, 3) if vel is None else vel,
+                                 angvel=torch.zeros(E, N, 3) if angvel is None else angvel, env_mask=mask)
+        elif vel is not None or angvel is not None or ori is not None:
+            self.shard.set_state(ori=ori, vel=vel, angvel=angvel, env_mask=mask)
+        if self.RESET_CONTROLLERS:
+            self.shard.pid_reset(env_mask=mask)
+        self._reset_step[mask] = self._global_step
+        xr = self._Xring
+        self._obs.write_into(xr.buf[xr.head])          # newest slice in place: unchanged for the envs that were not reset
+        if self.K_HOPS > 0:
+            w = xr.window()
+            w[1:, mask] = w[0, mask]
+        for ring in (self._Apacked, self._Adense):
+            if ring is not None:
+                ring.window()[:, mask] = 0
+        Xk = self.get_Xk()
+        self.last_obs = Xk
+        return Xk
+
+    def env_steps(self):
+        """Steps since each env's own last reset, int64 (E,) on the device."""
+        return self._global_step - self._reset_step
 
     def set(self, pos=None, ori=None, vel=None, angvel=None):  # MRS.py:196-205
         self.env.set_state(pos=pos, ori=ori, vel=vel, angvel=angvel)
@@ -420,6 +475,18 @@ class MRS(_EnvBase):
         done = self.done_fn(Xlast=self.last_obs, **kw)
         self.last_loop_time = time.monotonic()
         self.steps_since_reset += 1
+        self._global_step += 1
+        if self.AUTO_RESET:
+            # gym vector-env convention: the observation returned for a finished env is its first one after the
+            # reset; the terminal stack is kept in info["terminal_X"].  A tensor-valued `done` costs one host sync.
+            if isinstance(done, torch.Tensor) and done.numel() == E and E > 1:
+                dmask = done.to(self.device).to(torch.bool).reshape(E)
+                if bool(dmask.any()):
+                    info["terminal_X"], info["reset_mask"] = (Xk if self._copies() else Xk.clone()), dmask
+                    Xk = self.reset_envs(dmask)
+            elif bool(done):
+                info["terminal_X"] = Xk if self._copies() else Xk.clone()
+                Xk = self.reset()
         return Xk, reward, done, info
 
     def get_env(self):  # MRS.py:280-293

@@ -221,3 +221,77 @@ def test_checkpoint_roundtrip():
     env.load_state_dict(sd)
     b = [env.step(torch.full((N, 3), -0.1))[0].clone() for _ in range(5)]
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_reset_envs_touches_only_the_selected_envs():
+    """Per-env reset (vectorised extension): the selected envs behave like a fresh MRS.reset (MRS.py:174-192: new
+    state, zero velocities, X history padded with the new observation, A history empty), the others keep state,
+    controller memory and history bit for bit."""
+    import mrsgym_amd
+    E, N, K = 4, 8, 2
+    pos, eul = grid_spawn(E, N, seed=3)
+    kw = dict(N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.0, START_POS=torch.from_numpy(pos),
+              ACTION_TYPE="set_target_vel")
+    env, ref = mrsgym_amd.make('mrs-v0', **kw), mrsgym_amd.make('mrs-v0', **kw)
+    for e_ in (env, ref):
+        e_.reset(ori=torch.from_numpy(eul))
+    acts = ActionStream("set_target_vel", E, N, pos, seed=5, coherent=True)
+    for t in range(15):
+        a = torch.from_numpy(acts(t)).cuda()
+        env.step(a); ref.step(a)
+    mask = torch.tensor([False, True, False, True])
+    newpos = torch.from_numpy(pos) + torch.tensor([0.1, -0.2, 0.5])
+    Xk = env.reset_envs(mask, pos=newpos, ori=torch.from_numpy(eul))
+    Xr = ref.get_Xk()
+    assert Xk.shape == (E, K + 1, N, 6)
+    keep = ~mask
+    assert torch.equal(Xk[keep.cuda()], Xr[keep.cuda()])                          # untouched envs: history intact
+    for k in range(K + 1):                                                         # reset envs: padded with the new X
+        assert torch.allclose(Xk[mask.cuda()][:, k, :, :3].cpu(), newpos[mask].float(), atol=1e-6)
+        assert float(Xk[mask.cuda()][:, k, :, 3:].abs().max()) == 0.0
+    for name in ("pos", "quat", "vel", "angvel", "pid"):
+        a, b = getattr(env.shard, name), getattr(ref.shard, name)
+        va, vb = a.view(a.shape[0], E, N), b.view(b.shape[0], E, N)
+        assert torch.equal(va[:, keep.cuda()], vb[:, keep.cuda()]), name          # state + controller memory intact
+    assert torch.equal(env.env_steps().cpu(), torch.tensor([15, 0, 15, 0]))
+    # next step: A history of the reset envs is [A_new, 0, 0]; the others carry on exactly like the reference run
+    a = torch.from_numpy(acts(15)).cuda()
+    X1, _, _, info1 = env.step(a)
+    X2, _, _, info2 = ref.step(a)
+    assert torch.equal(X1[keep.cuda()], X2[keep.cuda()]) and torch.equal(info1["A"][keep.cuda()], info2["A"][keep.cuda()])
+    A = info1["A"][mask.cuda()]
+    assert float(A[:, 1:].abs().max()) == 0.0 and float(A[:, 0].sum()) > 0
+    # default spawn through the env mask: only the selected envs move, min separation holds (MRS.py:137-153)
+    env2 = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=1)
+    before = env2.shard.view(env2.shard.pos).clone()
+    env2.reset_envs(mask)
+    after = env2.shard.view(env2.shard.pos)
+    assert torch.equal(after[keep.cuda()], before[keep.cuda()]) and not torch.equal(after[mask.cuda()], before[mask.cuda()])
+    d = torch.cdist(after[mask.cuda()].float(), after[mask.cuda()].float()) + 10 * torch.eye(N, device="cuda")
+    assert float(d.min()) >= 0.6 - 1e-6
+
+
+def test_auto_reset_on_done_mask():
+    """AUTO_RESET: envs flagged by a tensor-valued done_fn restart inside step(); the returned stack is their first
+    observation after the reset, the terminal one is in info (gym vector-env convention)."""
+    import mrsgym_amd
+    E, N = 3, 4
+    pos, eul = grid_spawn(E, N, seed=1)
+
+    def done_fn(X=None, **kw):   # an env is done once its first agent has climbed above z = 2.2
+        return X[:, 0, 0, 2] > 2.2
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=1, START_POS=torch.from_numpy(pos),
+                          ACTION_TYPE="set_target_vel", done_fn=done_fn, AUTO_RESET=True)
+    start_z = env.get_Xk()[:, 0, 0, 2].clone()
+    up = torch.zeros(E, N, 3, device="cuda"); up[0, :, 2] = 2.0; up[2, :, 2] = 0.5     # env 0 climbs fast, env 1 hovers
+    fired = None
+    for t in range(400):
+        X, r, done, info = env.step(up)
+        if "reset_mask" in info:
+            fired = (t, info["reset_mask"].cpu().tolist(), info["terminal_X"], X)
+            break
+    assert fired is not None and fired[1][0] and not fired[1][1]
+    t, m, Xterm, X = fired
+    assert float(Xterm[0, 0, 0, 2]) > 2.2 and abs(float(X[0, 0, 0, 2]) - float(start_z[0])) < 1e-6
+    assert torch.equal(X[0, 0], X[0, 1])                       # history of the restarted env is padded with its new X
+    assert env.env_steps().cpu().tolist()[0] == 0 and env.env_steps().cpu().tolist()[1] == t + 1
