@@ -156,6 +156,14 @@ int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int
 int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_index_base, double agent_radius,
               const float ori_lo[3], const float ori_hi[3], int max_rounds, const uint8_t *env_mask, void *stream);
 
+/* A caller of the path, fused: the Reynolds flocking expert the reference's data generator
+ * drives the env with -- examples/simulating_data/helper/Reynolds.py:80-110 (forward_batch) with the controller
+ * of helper/Reynolds_Node.py:26-38, in the configuration its own caller uses (gen_data.py:33: K = 1).
+ * x_prev: (E,N,D) float32 row-major, D >= 6 = cat(pos, vel, ...) of the PREVIOUS step (history slot 1 of the
+ * K_HOPS ring can be passed as is); actions: (E,N,3) float32 target velocities.  forward_batch ignores the
+ * adjacency it is handed (it substitutes ones - eye, Reynolds.py:83), so none is taken here. */
+int mrs_reynolds(MrsHandle *h, const float *x_prev, int D, float *actions, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

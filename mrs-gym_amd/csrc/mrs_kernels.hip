@@ -706,6 +706,56 @@ __global__ void k_spawn(const SpawnArgs S)
     }
 }
 
+// ------------------------------------------------------------------------------- Reynolds expert
+// Reynolds.forward_batch (examples/simulating_data/helper/Reynolds.py:80-110) + Reynolds_Controller.forward_batch
+// (Reynolds_Node.py:26-38) for K = 1: all-to-all neighbourhood of the previous step's states.  One lane per
+// agent, the env's positions and velocities staged in LDS, float32 with the operation order of
+// oracle/mrs_oracle.c:orc_reynolds (bit-identical to it; the reference's torch reductions sum in their own order).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_reynolds(const float *__restrict__ x_prev, float *__restrict__ actions, int E, int N, int D, int epb)
+{
+    extern __shared__ float4 lds_tile[]; // [BLOCK] positions, [BLOCK] velocities
+    const int tid = threadIdx.x;
+    const int el = tid / N;
+    const int i = tid - el * N;
+    const int e = blockIdx.x * epb + el;
+    const bool live = (el < epb) && (e < E);
+    float xi[6] = {0, 0, 0, 0, 0, 0};
+    const size_t a = live ? (size_t)e * N + i : 0;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xi[k] = x_prev[a * D + k];
+    }
+    lds_tile[tid] = make_float4(xi[0], xi[1], xi[2], 0.f);
+    lds_tile[BLOCK + tid] = make_float4(xi[3], xi[4], xi[5], 0.f);
+    __syncthreads();
+    if (!live) return;
+    const float4 *P = lds_tile + el * N, *V = lds_tile + BLOCK + el * N;
+    float rp[3] = {0, 0, 0}, inv[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
+    for (int j = 0; j < N; ++j) {
+        if (j == i) continue; // A_ii = 0: every term of the diagonal is an exact zero
+        const float4 pj = P[j], vj = V[j];
+        const float np0 = f32sub(pj.x, xi[0]), np1 = f32sub(pj.y, xi[1]), np2 = f32sub(pj.z, xi[2]);
+        const float nv0 = f32sub(vj.x, xi[3]), nv1 = f32sub(vj.y, xi[4]), nv2 = f32sub(vj.z, xi[5]);
+        const float dp = f32sqrt(f32fma(np2, np2, f32fma(np1, np1, f32mul(np0, np0))));
+        const float dv = f32sqrt(f32fma(nv2, nv2, f32fma(nv1, nv1, f32mul(nv0, nv0))));
+        const float den = f32add(0.0f, f32mul(f32mul(dp, dp), dp)); // (A - 1) + |n|^3 with A = 1
+        rp[0] = f32add(rp[0], f32mul(np0, dp)); rp[1] = f32add(rp[1], f32mul(np1, dp)); rp[2] = f32add(rp[2], f32mul(np2, dp));
+        inv[0] = f32add(inv[0], f32div(np0, den)); inv[1] = f32add(inv[1], f32div(np1, den)); inv[2] = f32add(inv[2], f32div(np2, den));
+        rv[0] = f32add(rv[0], f32mul(nv0, dv)); rv[1] = f32add(rv[1], f32mul(nv1, dv)); rv[2] = f32add(rv[2], f32mul(nv2, dv));
+    }
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = f32mul(0.5f, f32add(f32add(rp[k], f32mul(3.0f, -inv[k])), f32mul(3.0f, rv[k])));
+    const float no = f32sqrt(f32fma(o[2], o[2], f32fma(o[1], o[1], f32mul(o[0], o[0]))));
+    const float mag = f32div(no > 1.0f ? 1.0f : no, no); // torch.clamp(norm, max=1) / norm
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = f32mul(o[k], mag);
+        actions[a * 3 + k] = (v != v) ? 0.0f : v; // actions[isnan] = 0 (Reynolds.py:105)
+    }
+}
+
 // ------------------------------------------------------------------------------------------- host
 struct MrsHandle {
     MrsParams P;
@@ -1026,6 +1076,18 @@ extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *e
     hipLaunchKernelGGL(k_pid_reset, dim3((unsigned)((T + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, *b, env_mask, h->N, T);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_pid_reset launch");
+}
+
+extern "C" int mrs_reynolds(MrsHandle *h, const float *x_prev, int D, float *actions, void *stream)
+{
+    if (!h || !x_prev || !actions) return fail(MRS_E_ARG, "mrs_reynolds: NULL argument");
+    if (D < 6) return fail(MRS_E_ARG, "mrs_reynolds: D must be >= 6 (pos, vel lead the state vector)");
+    const int grid = (h->E + h->epb - 1) / h->epb;
+    const size_t lds = 2 * (size_t)h->block * sizeof(float4);
+    if (h->block == 256) hipLaunchKernelGGL((k_reynolds<256>), dim3(grid), dim3(256), lds, (hipStream_t)stream, x_prev, actions, h->E, h->N, D, h->epb);
+    else hipLaunchKernelGGL((k_reynolds<1024>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, x_prev, actions, h->E, h->N, D, h->epb);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_reynolds launch");
 }
 
 extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_index_base, double agent_radius,

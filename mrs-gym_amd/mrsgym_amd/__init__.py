@@ -9,6 +9,7 @@ from .native import MrsNativeError, SwarmShard, default_params, derived  # noqa:
 __all__ = ["native", "MrsNativeError", "SwarmShard", "default_params", "derived"]
 try:
     from .mrs import MRS, make  # noqa: F401
-    __all__ += ["MRS", "make"]
+    from .reynolds import Reynolds  # noqa: F401
+    __all__ += ["MRS", "make", "Reynolds"]
 except ImportError:  # pragma: no cover - during bootstrap only
     pass

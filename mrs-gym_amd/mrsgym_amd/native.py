@@ -29,7 +29,7 @@ STATUS_NAN_ACTION, STATUS_SPAWN_FAIL = 1, 2
 EXPORTS = [
     "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
     "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
-    "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn",
+    "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn", "mrs_reynolds",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
         L.mrs_adjacency_expand.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mrs_spawn.argtypes = [vp, C.POINTER(MrsBuffers), C.c_uint64, C.c_int64, C.c_double,
                                 C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, vp, vp]
+        L.mrs_reynolds.argtypes = [vp, vp, C.c_int, vp, vp]
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
@@ -291,6 +292,18 @@ class SwarmShard:
         b = self._buffers()
         _check(self.L.mrs_spawn(self.h, C.byref(b), int(seed) & (2 ** 64 - 1), int(env_index_base), float(agent_radius),
                                 lo, hi, int(max_rounds), _ptr(mask), _stream(self.device)), "mrs_spawn")
+
+    def reynolds(self, x_prev, actions_out=None):
+        """Reynolds expert (mrs_reynolds): x_prev (E,N,D>=6) float32 device tensor -> (E,N,3) target velocities."""
+        if x_prev.dtype != torch.float32 or not x_prev.is_contiguous() or x_prev.device != self.device:
+            x_prev = x_prev.to(device=self.device, dtype=torch.float32).contiguous()
+        D = x_prev.numel() // (self.E * self.N)
+        if D * self.E * self.N != x_prev.numel():
+            raise ValueError("x_prev has %d elements, expected (E=%d, N=%d, D)" % (x_prev.numel(), self.E, self.N))
+        if actions_out is None:
+            actions_out = torch.empty(self.E, self.N, 3, dtype=torch.float32, device=self.device)
+        _check(self.L.mrs_reynolds(self.h, _ptr(x_prev), D, _ptr(actions_out), _stream(self.device)), "mrs_reynolds")
+        return actions_out
 
     # ------------------------------------------------------------------ views (E,N,k), zero-copy
     def view(self, t):

@@ -88,6 +88,7 @@ def lib():
         _lib.orc_observe.argtypes = [dp, dp, dp, dp, fp, fp, fp, fp, fp]
         _lib.orc_observe_batch.argtypes = [C.c_int, dp, dp, dp, dp, fp, fp, fp, fp]
         _lib.orc_adjacency_batch.argtypes = [C.c_int, C.c_int, fp, C.c_double, fp]
+        _lib.orc_reynolds.argtypes = [C.c_int, C.c_int, C.c_int, fp, fp]
         _lib.orc_pos_control.argtypes = [PP, SP, fp, fp, fp, fp, fp, dp]
         _lib.orc_vel_control.argtypes = [PP, SP, fp, fp, fp, fp, dp]
         _lib.orc_accel_control.argtypes = [PP, SP, dp, fp, fp, dp]
@@ -221,6 +222,15 @@ def adjacency(pos, comm_range):
     A = np.zeros((n, n), np.float32)
     lib().orc_adjacency(n, _f(pos), float(comm_range), _f(A))
     return A
+
+
+def reynolds(x_prev):
+    """Reynolds.forward_batch of the reference's data generator on x_prev (E,N,D>=6) float32 -> (E,N,3)."""
+    x = np.ascontiguousarray(x_prev, dtype=np.float32)
+    E, N, D = x.shape
+    out = np.zeros((E, N, 3), np.float32)
+    lib().orc_reynolds(E, N, D, _f(x), _f(out))
+    return out
 
 
 def integrate(params, pos, quat, vel, angvel, force_body, torque_body):

@@ -454,6 +454,52 @@ void orc_adjacency_batch(int E, int n, const float *pos, double comm_range, floa
     for (int e = 0; e < E; ++e) orc_adjacency(n, pos + (size_t)e * n * 3, comm_range, A + (size_t)e * n * n);
 }
 
+/* ------------------------------------------------------------- Reynolds expert (caller of the path)
+ * examples/simulating_data/helper/Reynolds.py:80-110 (forward_batch) with the controller of
+ * Reynolds_Node.py:26-38, for the configuration its own caller uses (gen_data.py:33: D >= 6, K = 1).
+ * forward_batch overwrites the adjacency it is given with ones - eye (Reynolds.py:83), takes the states of
+ * the PREVIOUS step Xs[..., 1] (:87) and reduces to
+ *     n_ij = x_j - x_i  (6 relative dims),
+ *     out_i = 0.5 (sum_j n_p |n_p| - 3 sum_j A_ij n_p / (A_ij - 1 + |n_p|^3) + 3 sum_j n_v |n_v|),
+ *     out_i *= min(|out_i|, 1) / |out_i|,   NaN -> 0  (:105).
+ * float32 throughout, norms as torch evaluates them (fma chain, see orc_adjacency); the sums over j run in
+ * index order here whereas torch's reduction order is its own: agreement to a few float32 ulp of the sum. */
+static float norm3f(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
+
+void orc_reynolds(int E, int n, int D, const float *x_prev, float *actions)
+{
+    for (int e = 0; e < E; ++e) {
+        const float *X = x_prev + (size_t)e * n * D;
+        for (int i = 0; i < n; ++i) {
+            float rp[3] = {0, 0, 0}, inv[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
+            for (int j = 0; j < n; ++j) {
+                const float A = (i == j) ? 0.0f : 1.0f;
+                float np_[3], nv[3];
+                for (int k = 0; k < 3; ++k) {
+                    /* Z[...,1] = A_ji Y_j - A_ij X_i, Z[...,0] = 0 in the relative dims (Reynolds.py:99-103) */
+                    np_[k] = A * X[j * D + k] - A * X[i * D + k];
+                    nv[k] = A * X[j * D + 3 + k] - A * X[i * D + 3 + k];
+                }
+                const float dp = norm3f(np_[0], np_[1], np_[2]), dv = norm3f(nv[0], nv[1], nv[2]);
+                const float den = (A - 1.0f) + dp * dp * dp;
+                for (int k = 0; k < 3; ++k) {
+                    rp[k] += np_[k] * dp;
+                    inv[k] += A * (np_[k] / den);
+                    rv[k] += nv[k] * dv;
+                }
+            }
+            float o[3];
+            for (int k = 0; k < 3; ++k) o[k] = 0.5f * ((1.0f * rp[k] + 3.0f * (-inv[k])) + 3.0f * rv[k]);
+            const float no = norm3f(o[0], o[1], o[2]);
+            const float mag = (no > 1.0f ? 1.0f : no) / no;     /* torch.clamp(norm, max=1) / norm */
+            for (int k = 0; k < 3; ++k) {
+                float v = o[k] * mag;
+                actions[((size_t)e * n + i) * 3 + k] = (v != v) ? 0.0f : v;
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------- integration */
 
 static void quat_to_matrix_bullet(const double q[4], double R[9])

@@ -106,6 +106,10 @@ void orc_adjacency(int n, const float *pos, double comm_range, float *A);
 
 void orc_adjacency_batch(int E, int n, const float *pos, double comm_range, float *A);
 
+/* Reynolds flocking expert (examples/simulating_data/helper/Reynolds.py:80-110, Reynolds_Node.py:26-38; D >= 6,
+ * K = 1): x_prev fp32 [E][N][D] = the PREVIOUS step's states, actions fp32 [E][N][3] */
+void orc_reynolds(int E, int n, int D, const float *x_prev, float *actions);
+
 /* One env step for E envs x N agents (MRS.py:240-257 without the callbacks).
  * Arrays are [E][N][k] row-major.  actions may be NULL (ORC_ACT_NONE).
  * speeds_out (optional) receives the rotor speeds used this step, [E][N][4] double;

@@ -295,3 +295,37 @@ def test_auto_reset_on_done_mask():
     assert float(Xterm[0, 0, 0, 2]) > 2.2 and abs(float(X[0, 0, 0, 2]) - float(start_z[0])) < 1e-6
     assert torch.equal(X[0, 0], X[0, 1])                       # history of the restarted env is padded with its new X
     assert env.env_steps().cpu().tolist()[0] == 0 and env.env_steps().cpu().tolist()[1] == t + 1
+
+
+def test_reynolds_expert_kernel(golden_dir):
+    """mrs_reynolds: bit-identical to the oracle restatement, within 2e-6 of the reference's own
+    forward_batch outputs (tests/golden/F7), in the reference's input layout, this library's stack layout and
+    straight from an env's history ring."""
+    import mrsgym_amd
+    d = np.load(os.path.join(golden_dir, "F7_reynolds.npz"))
+    for k in d.files:
+        if not k.endswith("_Xs"):
+            continue
+        Xs, want = d[k], d[k[:-3] + "_actions"]
+        B, N, D, _ = Xs.shape
+        model = mrsgym_amd.Reynolds(N=N, D=D, K=1, OUT_DIM=3)
+        got = model.forward(None, torch.from_numpy(Xs)).cpu().numpy()
+        assert np.array_equal(got, oracle.reynolds(Xs[..., 1])), k
+        assert np.abs(got - want).max() < 2e-6, k
+        stack = torch.from_numpy(np.ascontiguousarray(Xs.transpose(0, 3, 1, 2)))       # (B, K+1, N, D)
+        assert np.array_equal(model.forward_stack(stack).cpu().numpy(), got)
+    with pytest.raises(NotImplementedError):
+        mrsgym_amd.Reynolds(N=4, D=6, K=2)
+    # closed loop: the expert drives a small flock through the Gym surface, reading X(t-1) from the ring in place
+    E, N = 3, 12
+    pos, eul = grid_spawn(E, N, seed=2)
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=1, COMM_RANGE=2.5,
+                          START_POS=torch.from_numpy(pos), ACTION_TYPE="set_target_vel")
+    model = mrsgym_amd.Reynolds(N=N, D=6)
+    X = env.get_Xk()
+    for t in range(30):
+        a = model.from_env(env)
+        assert np.array_equal(a.cpu().numpy(), oracle.reynolds(X[:, 1].cpu().numpy()))
+        assert float(a.norm(dim=-1).max()) <= 1.0 + 1e-6
+        X, r, done, info = env.step(a)
+    assert torch.isfinite(X).all()

@@ -152,3 +152,22 @@ def test_F6_step_none_and_touchdown():
         assert np.abs(sw.wrench).max() == 0.0       # MRS.py:243-253: no set_actions => no rotor/aero forces
         np.testing.assert_allclose(_state(sw), d["state"][t], rtol=0, atol=1e-9)
     assert sw.pos[0, 0, 2] < 0.56 and abs(sw.vel[0, 0, 2]) < 0.05      # came to rest on the ground top (z = 0.5)
+
+
+def test_F7_reynolds_expert(golden_dir):
+    """oracle.reynolds vs the reference's Reynolds.forward_batch (examples/simulating_data/helper/Reynolds.py:80-110,
+    K=1).  float32; the reference's torch reductions sum over neighbours in their own order, hence not bit-exact:
+    |action| <= 1 by construction, tolerance 2e-6 absolute (measured 6.6e-7 at N=64).  Coincident agents give
+    0/0 = NaN -> 0 (Reynolds.py:105) in both."""
+    d = np.load(os.path.join(golden_dir, "F7_reynolds.npz"))
+    n = 0
+    for k in d.files:
+        if not k.endswith("_Xs"):
+            continue
+        Xs, want = d[k], d[k[:-3] + "_actions"]
+        got = oracle.reynolds(Xs[..., 1])
+        assert got.shape == want.shape and not np.isnan(got).any()
+        assert np.abs(got - want).max() < 2e-6, k
+        assert np.array_equal(got == 0, want == 0), k          # the NaN -> 0 rows coincide
+        n += 1
+    assert n == 4

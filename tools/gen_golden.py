@@ -438,13 +438,40 @@ def gen_F6(out):
     return cases
 
 
+def gen_F7(out):
+    """The Reynolds flocking expert the reference's data generator drives the env with
+    (examples/simulating_data/helper/Reynolds.py:80-110 forward_batch, Reynolds_Node.py:26-38), as called by
+    gen_data.py:33 (D=6, K=1).  Inputs in ITS layout (batch, N, D, K+1); plain torch, imported from where it lies."""
+    import torch
+    sys.path.insert(0, os.path.join(REF, "examples", "simulating_data"))
+    from helper.Reynolds import Reynolds
+    rng = np.random.default_rng(77)
+    data = {}
+    for N, B, D in ((3, 6, 6), (12, 5, 6), (64, 4, 6), (12, 3, 9)):
+        # swarm-like inputs: positions spread over a few metres, velocities ~ 1 m/s; one env with two coincident agents
+        Xs = np.concatenate([rng.normal(0, 1.5, (B, N, 3, 2)), rng.normal(0, 0.7, (B, N, D - 3, 2))], 2).astype(np.float32)
+        Xs[0, 1, :3, 1] = Xs[0, 0, :3, 1]
+        model = Reynolds(N=N, D=D, K=1, OUT_DIM=3)
+        with torch.no_grad():
+            act = model.forward(None, torch.from_numpy(Xs.copy()))
+        key = "N%d_D%d" % (N, D)
+        data[key + "_Xs"] = Xs
+        data[key + "_actions"] = act.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(out, "F7_reynolds.npz"), **data)
+    return sorted(k for k in data if k.endswith("_Xs"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="generate one fixture family only, e.g. F7")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     import scipy
     print("numpy", np.__version__, "scipy", scipy.__version__)
+    if args.only == "F7":
+        print("F7", gen_F7(args.out))
+        return
     mrsgym = import_reference(FakeBullet())
     print("F1 anchor", gen_F1(mrsgym, args.out))
     print("F2 nnls-branch fraction", gen_F2(mrsgym, args.out))
@@ -452,12 +479,14 @@ def main():
     gen_F4(mrsgym, args.out); print("F4 done")
     gen_F5(mrsgym, args.out); print("F5 done")
     print("F6", gen_F6(args.out))
+    print("F7", gen_F7(args.out))
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write("Golden fixtures generated by tools/gen_golden.py from the reference's own Python\n"
                 "(numpy %s, scipy %s).  Data only: inputs and expected outputs.\n"
                 "F1 QuadControl cascade, F2 nnlsRPM, F3 MRS.calc_A, F4 history deques, F5 spawn,\n"
                 "F6 full MRS.step() trajectories with pybullet replaced by the build's own oracle\n"
-                "integrator (pins everything except the Bullet integrator/contact: parity unpinned there).\n"
+                "integrator (pins everything except the Bullet integrator/contact: parity unpinned there),\n"
+                "F7 the Reynolds flocking expert of examples/simulating_data (forward_batch, D=6/9, K=1).\n"
                 % (np.__version__, scipy.__version__))
 
 
