@@ -321,3 +321,43 @@ def test_env_sharding_is_bitwise():
     for k in f:
         got = np.concatenate([_gpu_state(h)[k] for h in halves])
         assert np.array_equal(got, f[k]), k
+
+
+def test_one_launch_and_three_launch_steps_agree():
+    """mrs_step as ONE fused launch (default for N_AGENTS <= 256) and as k_step + k_contact + k_observe_adj
+    (MRS_STEP_SPLIT=1; the path N_AGENTS > 256 takes) run the same source arithmetic, through ground contact too
+    (SURVEY 8d workload: a part of the swarm is on the ground by step 300).  Compared step by step from identical
+    states (the three-launch shard is re-seeded from the fused one before every step: the workload is chaotic and
+    would amplify rounding differences otherwise).  Not bit-identical -- the compiler contracts a*b+c per kernel --
+    so: 1e-12 relative on the float64 state, 1e-6 on the float32 controller memory/observations, adjacency equal."""
+    import mrsgym_amd
+    E, N = 6, 64
+    pos, eul = grid_spawn(E, N, seed=4)
+    z = np.zeros((E, N, 3), np.float32)
+    shards = []
+    for split in ("0", "1"):
+        os.environ["MRS_STEP_SPLIT"] = split
+        try:
+            sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+        finally:
+            os.environ.pop("MRS_STEP_SPLIT", None)
+        shards.append((sh, torch.zeros(E, N, sh.D, device="cuda:0"), torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")))
+    (s0, o0, a0), (s1, o1, a1) = shards
+    grounded = 0
+    for atype in ("set_target_vel", "set_speeds", None):
+        acts = ActionStream(atype, E, N, pos, seed=9) if atype else None
+        s0.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+        s0.pid_reset()
+        for t in range(300):
+            a = torch.from_numpy(acts(t)).cuda() if atype else None
+            s1.load_state_dict(s0.state_dict())
+            for sh, obs, adj in shards:
+                sh.step(a, atype, obs_out=obs, adj_out=adj, comm_range=2.5)
+            for name in ("pos", "quat", "vel", "angvel"):
+                x0, x1 = getattr(s0, name), getattr(s1, name)
+                err = float(((x0 - x1).abs() / x0.abs().clamp(min=1.0)).max())
+                assert err < 1e-12, (atype, t, name, err)
+            assert float(torch.nan_to_num(s0.pid - s1.pid, nan=0.0).abs().max()) < 1e-6 * max(1.0, float(torch.nan_to_num(s0.pid).abs().max()))
+            assert float((o0 - o1).abs().max()) < 1e-6 and torch.equal(a0, a1), (atype, t)
+        grounded += int((s0.pos[2] < 0.52).sum())
+    assert grounded > 0      # some bodies did reach the ground (z of the resting hull centre is 0.5125)
