@@ -877,9 +877,12 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     hipGetDevice(&cur);
     hipSetDevice(device);
     const size_t ws_bytes = (2 + (size_t)n_envs * n_agents) * sizeof(int);
-    e = hipMalloc((void **)&h->ws, ws_bytes);
-    if (e == hipSuccess) e = hipMemset(h->ws, 0, ws_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
+    e = hipSuccess;
+    if (!h->fused) { // the one-launch step keeps its contact list and parked states in LDS
+        e = hipMalloc((void **)&h->ws, ws_bytes);
+        if (e == hipSuccess) e = hipMemset(h->ws, 0, ws_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
+    }
     if (e != hipSuccess) {
         if (h->ws) hipFree(h->ws);
         hipSetDevice(cur);
@@ -963,10 +966,12 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     A.actions = actions;
     // alternating counters: this step's k_step adds to ws[parity] (read by this step's k_contact) and
     // zeroes ws[parity^1] for the next step -- stream order makes that safe without a memset node
-    A.contact_count = h->ws + (h->step_parity & 1);
-    A.contact_count_next = h->ws + ((h->step_parity & 1) ^ 1);
-    A.contact_list = h->ws + 2;
-    A.contact_state = h->cs;
+    if (h->ws) {
+        A.contact_count = h->ws + (h->step_parity & 1);
+        A.contact_count_next = h->ws + ((h->step_parity & 1) ^ 1);
+        A.contact_list = h->ws + 2;
+        A.contact_state = h->cs;
+    }
     h->step_parity++;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
