@@ -126,6 +126,17 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *t
 }
 
 
+// N = 64: an env is exactly one wave, so its LDS position tile is written and read by the same wave and needs
+// no workgroup barrier -- LDS operations of one wave execute in order; this only pins the compiler's ordering.
+// (Every workgroup barrier couples four waves that sit on four different SIMDs and progress at different rates:
+// measured with clock64 stamps, waves spent ~10 % of their lifetime in the two barriers this replaces.)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 template <int BLOCK>
@@ -134,7 +145,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
     const bool n64 = (BLOCK == 256) && (A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
     else lds_tile[tid] = mine;
-    __syncthreads();
+    if (n64) wave_lds_sync(); else __syncthreads();
     if (n64) {
         // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
         // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     float act[4] = {0, 0, 0, 0};
     if (tid < A.epb) nanflag[tid] = 0;
     if (tid == 0) *ncontact = 0;
+    if (n64) __syncthreads(); // counters visible before any wave runs ahead; taken here, before a load is in flight
     if (live) {
         load_state(wb, la, T, p, q, v, w);
         if (ACT != MRS_ACT_NONE) {
@@ -220,17 +232,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     } else {
         lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     }
-    __syncthreads();
-    if (live && ACT != MRS_ACT_NONE) {
+    if (n64) wave_lds_sync(); else __syncthreads();
+    // MRS.py:247-248: any NaN in the env's action aborts that env's step
+    bool env_nan = false;
+    if (ACT != MRS_ACT_NONE) {
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < ADIM; ++k) bad |= isnan(act[k]);
-        if (bad) nanflag[el] = 1; // MRS.py:247-248: any NaN in the env's action aborts that env's step
+        if (n64) {
+            env_nan = __builtin_amdgcn_ballot_w64(live && bad) != 0; // the wave is the env
+        } else {
+            if (live && bad) nanflag[el] = 1;
+            __syncthreads();
+            env_nan = (el < A.epb) && nanflag[el];
+        }
     }
-    __syncthreads();
     const bool masked = live && A.mask && !A.mask[e];
-    const bool doit = live && !masked && !(ACT != MRS_ACT_NONE && nanflag[el]);
-    if (live && i == 0 && ACT != MRS_ACT_NONE && nanflag[el] && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
+    const bool doit = live && !masked && !env_nan;
+    if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
     int my_slot = -1;
     bool parked = false;

@@ -1,0 +1,29 @@
+"""Diagnostic: per-wave phase timestamps of the fused step kernel (ablation build libmrs_tl.so: lane 0 of every wave
+writes clock64() deltas into the rpm buffer).  MRS_HIP_LIB=build/abl/libmrs_tl.so python tools/timeline_probe.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np, torch, mrsgym_amd
+from mrsgym_amd.native import ACT
+from util_scenarios import ActionStream, grid_spawn
+E, N = 4096, 64
+pos, eul = grid_spawn(E, N); z = np.zeros((E, N, 3), np.float32)
+sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", want_rpm=True)
+sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
+table = [torch.from_numpy(acts(50 * k)).cuda() for k in range(20)]
+obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torch.int64, device="cuda")
+names = ["loads+tile+vote", "downwash", "controller", "forces+intvel", "barrier1", "own solve", "barrier2", "pose+store", "obs+adj(end)"]
+for T0 in (200, 800):
+    for t in range(T0 if T0 == 200 else 600):
+        sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
+    torch.cuda.synchronize()
+    tl = sh.rpm.flatten()[:E * 16].view(E, 16).cpu().numpy()[:, :9]      # one wave per env at N=64
+    print("after %d steps (clock64 ticks; mean over %d waves, [min..max] of the cumulative stamp)" % (T0, E))
+    prev = np.zeros(E)
+    for k, nm in enumerate(names):
+        col = tl[:, k]
+        valid = col > 0
+        d = (col - prev)[valid]
+        print("  %-18s +%8.0f   cumulative %8.0f [%8.0f .. %8.0f]" % (nm, d.mean() if d.size else 0, col[valid].mean() if valid.any() else 0, col[valid].min() if valid.any() else 0, col[valid].max() if valid.any() else 0))
+        prev = np.where(valid, col, prev)
