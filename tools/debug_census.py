@@ -1,24 +1,22 @@
-"""Census of the bench workload's swarm state over time (diagnostic)."""
+"""Diagnostic: how are the grounded bodies spread over envs on the bench workload?  (per-env count of bodies that
+the step kernel queues for the contact solve: z - sqrt(r^2 + hl^2) - threshold <= ground)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
+from mrsgym_amd.native import ACT
 from util_scenarios import ActionStream, grid_spawn
-E, N = 1024, 64
-pos, eul = grid_spawn(E, N)
-z = np.zeros((E, N, 3), np.float32)
+E, N = 4096, 64
+pos, eul = grid_spawn(E, N); z = np.zeros((E, N, 3), np.float32)
 sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
 acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
-a = None
+table = [torch.from_numpy(acts(50 * k)).cuda() for k in range(24)]
+bound = (0.06 ** 2 + 0.0125 ** 2) ** 0.5 + 0.02 + 0.5
 for t in range(1100):
-    if t % 50 == 0:
-        a = torch.from_numpy(acts(t)).cuda()
-    sh.step(a, "set_target_vel")
-    if t % 100 == 99:
-        p = sh.view(sh.pos); v = sh.view(sh.vel)
-        bad = ~torch.isfinite(p).all(-1)
-        low = (p[..., 2] < 0.6) & ~bad
-        fast = (v.norm(dim=-1) > 5) & ~bad
-        print(t, "non-finite %.4f  grounded(z<0.6) %.3f  |v|>5 %.3f  max|p| %.1f" % (
-            bad.float().mean(), low.float().mean(), fast.float().mean(), float(p[~bad].abs().max())), flush=True)
+    sh.step_ptr(table[t // 50], ACT["set_target_vel"], 0, 0, float("nan"))
+    if t in (99, 299, 499, 699, 899, 1099):
+        c = (sh.view(sh.pos)[:, :, 2] <= bound).sum(1).cpu().numpy()
+        h = np.bincount(np.minimum(c, 64), minlength=65)
+        print("step %4d: grounded %5.1f %%; envs with 0: %4d, 1-4: %4d, 5-16: %4d, 17-32: %4d, 33-63: %4d, all 64: %4d; workgroups (4 envs) with 0: %d"
+              % (t + 1, 100 * c.sum() / (E * N), h[0], h[1:5].sum(), h[5:17].sum(), h[17:33].sum(), h[33:64].sum(), h[64], int((c.reshape(-1, 4).sum(1) == 0).sum())), flush=True)
