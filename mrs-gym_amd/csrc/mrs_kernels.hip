@@ -943,8 +943,8 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
     int cur = 0;
-    hipGetDevice(&cur);
-    hipSetDevice(device);
+    (void)hipGetDevice(&cur);
+    if ((e = hipSetDevice(device)) != hipSuccess) { delete h; return hipfail(e, "mrs_create hipSetDevice"); }
     const size_t ws_bytes = (2 + (size_t)n_envs * n_agents) * sizeof(int);
     e = hipSuccess;
     if (!h->fused) { // the one-launch step keeps its contact list and parked states in LDS
@@ -953,12 +953,12 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
     if (e != hipSuccess) {
-        if (h->ws) hipFree(h->ws);
-        hipSetDevice(cur);
+        if (h->ws) (void)hipFree(h->ws);
+        (void)hipSetDevice(cur);
         delete h;
         return hipfail(e, "mrs_create workspace");
     }
-    hipSetDevice(cur);
+    (void)hipSetDevice(cur);
     *out = h;
     return 0;
 }
@@ -969,10 +969,10 @@ extern "C" void mrs_destroy(MrsHandle *h)
     if (h->ws) {
         int cur = 0;
         if (hipGetDevice(&cur) == hipSuccess) {
-            hipSetDevice(h->device);
-            hipFree(h->ws);
-            if (h->cs) hipFree(h->cs);
-            hipSetDevice(cur);
+            (void)hipSetDevice(h->device);
+            (void)hipFree(h->ws);
+            if (h->cs) (void)hipFree(h->cs);
+            (void)hipSetDevice(cur);
         }
     }
     delete h;
@@ -1110,7 +1110,7 @@ extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float 
     return e == hipSuccess ? 0 : hipfail(e, "mrs_adjacency_expand launch");
 }
 
-static int launch_set(MrsHandle *h, const SetArgs &S, hipStream_t st)
+static int launch_set(MrsHandle *, const SetArgs &S, hipStream_t st)
 {
     const int block = 256;
     const unsigned grid = (unsigned)((S.T + block - 1) / block);
