@@ -150,26 +150,31 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
         // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
         // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
         // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
-        // it is relative bit 64-k; k = 32 is tested by both ends.  All shifts are immediates on 32-bit
-        // halves; one 64-bit rotate by the lane index at the end turns relative into absolute columns.
+        // it is relative bit 64-k; k = 32 is tested by both ends.  One 64-bit rotate by the lane index at
+        // the end turns relative into absolute columns.
         if (live) {
             const int lane = tid & 63;
             const float4 *nb = lds_tile + el * 128 + lane;
             const int lane4 = lane << 2;
-            uint32_t lo = 0, hi = 0; // relative bits 1..31 in lo, 32..63 in hi
+            // own verdicts at bit k of `lo`; the SAME word travels to lane i+k, whose verdicts from below
+            // collect in `hr` at bit k too and are mirrored into place (relative bit 64-k) by one v_bfrev at
+            // the end: one select and two ORs per pair, no per-pair shifts
+            uint32_t lo = 0, hr = 0, top = 0;
 #pragma unroll
             for (int k = 1; k <= 32; ++k) {
                 const float4 pj = nb[k];
                 const float dx = f32sub(mine.x, pj.x), dy = f32sub(mine.y, pj.y), dz = f32sub(mine.z, pj.z);
                 const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
-                const uint32_t close = A.comm_inf ? 1u : (uint32_t)(d2 <= A.d2_thresh);
+                const bool close = A.comm_inf || (d2 <= A.d2_thresh);
                 if (k < 32) {
-                    lo |= close << k;
-                    hi |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)close) << (32 - k);
+                    const uint32_t bit = close ? (1u << k) : 0u;
+                    lo |= bit;
+                    hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
                 } else {
-                    hi |= close; // relative bit 32
+                    top = close ? 1u : 0u; // relative bit 32: tested by both ends
                 }
             }
+            const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
             const uint64_t rel = ((uint64_t)hi << 32) | lo;
             row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
         }
