@@ -361,3 +361,48 @@ def test_one_launch_and_three_launch_steps_agree():
             assert float((o0 - o1).abs().max()) < 1e-6 and torch.equal(a0, a1), (atype, t)
         grounded += int((s0.pos[2] < 0.52).sum())
     assert grounded > 0      # some bodies did reach the ground (z of the resting hull centre is 0.5125)
+
+
+def test_full_size_bench_workload_properties():
+    """BASELINE.json configs[2] at full size (N=64 x 4096 envs, the bench workload, 300 steps into ground contact),
+    checked through size-independent properties: (a) envs are independent and the kernel is deterministic -- 4096
+    copies of ONE env fed the same actions stay bitwise identical to each other; (b) the first envs of the real
+    workload follow the CPU oracle; (c) quaternions stay unit, adjacency rows are symmetric with a zero diagonal
+    and agree with a float64 recount away from the threshold."""
+    import mrsgym_amd
+    E, N, R = 4096, 64, 5.0
+    pos, eul = grid_spawn(E, N)
+    z = np.zeros((E, N, 3), np.float32)
+    acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
+    # (a) identical envs
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    one = lambda x: np.broadcast_to(x[:1], x.shape).copy()
+    sh.set_state(pos=one(pos), ori=one(eul), vel=z, angvel=z)
+    obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    for t in range(300):
+        sh.step(torch.from_numpy(one(acts(t))).cuda(), "set_target_vel", obs_out=obs, adj_out=adj, comm_range=R)
+    for name in ("pos", "quat", "vel", "angvel", "pid"):
+        v = getattr(sh, name); v = v.view(v.shape[0], E, N)
+        assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(v[:, :1]).expand_as(v)), name
+    assert torch.equal(obs, obs[:1].expand_as(obs)) and torch.equal(adj, adj[:1].expand_as(adj))
+    assert float(sh.pos[2].min()) < 0.6                                    # the copies did reach the ground
+    # (b) + (c) the real workload
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z); sh.pid_reset()
+    n_or = 4
+    sw = oracle.OracleSwarm(n_or, N)
+    sw.set_state(pos=pos[:n_or].astype(np.float64), euler=eul[:n_or], vel=z[:n_or].astype(np.float64), angvel=z[:n_or].astype(np.float64))
+    for t in range(60):          # (the workload is chaotic: float32 read-back noise grows ~1 decade per 60 steps)
+        a = acts(t)
+        sh.step(torch.from_numpy(a).cuda(), "set_target_vel", obs_out=obs, adj_out=adj, comm_range=R)
+        sw.step(a[:n_or], "set_target_vel")
+    g = _gpu_state(sh)
+    assert np.abs(g["pos"][:n_or] - sw.pos).max() < 2e-5 and np.abs(g["vel"][:n_or] - sw.vel).max() < 2e-5
+    qn = (sh.quat ** 2).sum(0)
+    assert float((qn - 1).abs().max()) < 1e-12
+    rows = adj[:, :, 0].cpu().numpy().astype(np.uint64)                      # (E,N) one word per row
+    bits = ((rows[:, :, None] >> np.arange(N, dtype=np.uint64)[None, None, :]) & np.uint64(1)).astype(bool)   # (E,i,j)
+    assert not bits[:, np.arange(N), np.arange(N)].any() and np.array_equal(bits, bits.transpose(0, 2, 1))
+    p64 = sh.view(sh.pos).cpu().numpy()
+    d = np.linalg.norm(p64[:, :, None, :] - p64[:, None, :, :], axis=-1)
+    clear = np.abs(d - R) > 1e-4
+    assert np.array_equal(bits[clear], ((d <= R) & ~np.eye(N, dtype=bool)[None])[clear])
