@@ -10,6 +10,7 @@ __all__ = ["native", "MrsNativeError", "SwarmShard", "default_params", "derived"
 try:
     from .mrs import MRS, make  # noqa: F401
     from .reynolds import Reynolds  # noqa: F401
-    __all__ += ["MRS", "make", "Reynolds"]
+    from .rollout import RolloutLog  # noqa: F401
+    __all__ += ["MRS", "make", "Reynolds", "RolloutLog"]
 except ImportError:  # pragma: no cover - during bootstrap only
     pass

@@ -92,3 +92,44 @@ def test_default_spawn_distribution_properties():
     x = randrange(torch.tensor([0., 0., -1.]), torch.tensor([0., 0., 1.]))
     assert x.shape == (3,) and x[0] == 0 and abs(float(x[2])) <= 1
     assert totensor([1, 2]).tolist() == [1, 2]
+
+
+def test_rollout_log_writes_the_reference_trainer_dict(tmp_path):
+    """RolloutLog.save_trainer: the dict of deques Trainer.save_trainer writes (examples/simulating_data/helper/
+    Trainer.py:43-61, :89-108) -- one (N,N) float32 A, (N,D) X, bool done, (N,3) expert and a context dict per
+    sample, env after env in time order, the last sample of every env closing its episode.  (Checked once in the
+    build container against the reference's own Trainer.load_trainer_dict / get_episodes / get_batch: 4 episodes,
+    X (4,6,5,6) for this very input.)  Pure torch: runs on the CPU here, on device buffers in use."""
+    import torch
+    from collections import deque
+    from mrsgym_amd.rollout import RolloutLog
+    E, N, D, T = 3, 5, 6, 7
+    log = RolloutLog(E, N, D, capacity=16, device="cpu")
+    torch.manual_seed(0)
+    Xs, As, Ex = [], [], []
+    for t in range(T):
+        X = torch.randn(E, N, D)
+        A = ((torch.rand(E, N, N) > 0.5).float()) * (1 - torch.eye(N))
+        ex = torch.randn(E, N, 3)
+        if t % 2:       # packed rows in, as MRS(A_FORMAT="packed") hands them over
+            packed = (A.to(torch.int64) << torch.arange(N)).sum(-1, keepdim=True)
+            log.set_state(packed, X, done=torch.tensor([t == 3, False, False]), expert=ex)
+        else:
+            log.set_state(A, X, done=torch.tensor([t == 3, False, False]), expert=ex)
+        Xs.append(X); As.append(A); Ex.append(ex)
+    assert len(log) == T and torch.equal(log.dense_A(), torch.stack(As))
+    path = str(tmp_path / "flocking.pt")
+    log.save_trainer(path)
+    data = torch.load(path, weights_only=False)        # a file this test wrote itself
+    assert sorted(data) == ["history", "iter", "sample_idxs", "sample_weights"]
+    h = data["history"]
+    assert sorted(h) == ["A", "X", "context", "done", "expert"] and all(isinstance(v, deque) and len(v) == E * T for v in h.values())
+    for e in range(E):
+        for t in range(T):
+            k = e * T + t
+            assert torch.equal(h["X"][k], Xs[t][e]) and torch.equal(h["A"][k], As[t][e]) and torch.equal(h["expert"][k], Ex[t][e])
+            assert h["A"][k].dtype == torch.float32 and h["context"][k] == {}
+            assert h["done"][k] == (t == T - 1 or (e == 0 and t == 3))
+    with pytest.raises(IndexError):
+        for _ in range(20):
+            log.set_state(As[0], Xs[0])
