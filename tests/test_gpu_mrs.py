@@ -329,3 +329,40 @@ def test_reynolds_expert_kernel(golden_dir):
         assert float(a.norm(dim=-1).max()) <= 1.0 + 1e-6
         X, r, done, info = env.step(a)
     assert torch.isfinite(X).all()
+
+
+def test_data_generation_loop_like_the_reference_example():
+    """The reference's data generator (examples/simulating_data/gen_data.py + helper/DataGenerator.py:8-47), vectorised:
+    Reynolds expert -> leader override -> log sample -> env.step, episodes end when an agent loses all neighbours
+    (gen_data.py:57-61) or after episode_length steps, finished envs restart on their own (AUTO_RESET)."""
+    import mrsgym_amd
+    from mrsgym_amd.util import CombinedDistribution
+    from torch.distributions import Normal, Uniform
+    E, N, STEPS, EP_LEN = 16, 12, 60, 25
+    dist = CombinedDistribution([Normal(torch.zeros(N, 2), 1.25), Uniform(2.0 * torch.ones(N, 1), 5.0 * torch.ones(N, 1))],
+                                mixer='cat', dim=1)                              # gen_data.py:27-29
+
+    def done_fn(A=None, steps_since_reset=0, env=None, **kw):                     # gen_data.py:57-61, per env
+        isolated = (A[:, 0].sum(dim=-1) == 0).any(dim=-1)
+        return isolated | (mrs.env_steps() + 1 >= EP_LEN)
+    mrs = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=1, COMM_RANGE=2.5, START_POS=dist,
+                          ACTION_TYPE='set_target_vel', done_fn=done_fn, AUTO_RESET=True, SEED=3)
+    model = mrsgym_amd.Reynolds(N=N, D=6, K=1, OUT_DIM=3)
+    log = mrsgym_amd.RolloutLog(E, N, 6, capacity=STEPS)
+    X = mrs.get_Xk()
+    A = mrs.calc_Ak()                                                           # DataGenerator.py:22
+    resets = 0
+    for t in range(STEPS):
+        action = model.from_env(mrs)
+        expert = action.clone()
+        action[:, 0, :] = torch.tensor([0.3, 0.0, 0.0], device=action.device)     # the leader's own velocity (gen_data.py:76-88)
+        Xn, r, done, info = mrs.step(action)
+        log.set_state(A[:, 0], X[:, 0], done=done, expert=expert)
+        resets += int(done.sum())
+        X, A = Xn, info["A"]
+    assert len(log) == STEPS and resets >= E * (STEPS // EP_LEN)                  # every env restarted at least twice
+    d = log.trainer_dict()["history"]
+    assert len(d["X"]) == E * STEPS and sum(d["done"]) >= resets
+    ex = torch.stack(list(d["expert"]))
+    assert torch.isfinite(ex).all() and float(ex.norm(dim=-1).max()) <= 1.0 + 1e-6
+    assert torch.isfinite(torch.stack(list(d["X"]))).all()
