@@ -264,6 +264,43 @@ MRS_DEV void observe(const double p[3], const double q[4], const double v[3], co
     }
 }
 
+// observe<true,true> plus Re = from_euler('xyz', float32 euler read-back).as_matrix() -- the matrix the attitude
+// controller rebuilds from the angles it was handed (QuadControl.py:99) -- WITHOUT evaluating sin/cos again:
+// theta = atan2(y, x) has sin = y/h, cos = x/h exactly, and its float32 rounding moves it by d = fl32(theta) - theta,
+// |d| <= 2^-24 |theta|, so (sin, cos)(theta + d) = (s + c d - s d^2/2, c - s d - c d^2/2) to 1e-21.  All three angles
+// share h = |(R21, R22)| = cos(pitch): ~35 instructions instead of three range-reduced sincos (~105).
+MRS_DEV void rot_small(double s, double c, double d, double &so, double &co)
+{
+    const double t = 0.5 * d * d;
+    so = __builtin_fma(c, d, s) - s * t;
+    co = __builtin_fma(-s, d, c) - c * t;
+}
+MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re)
+{
+    o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
+    o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
+    o.wx = (float)w[0]; o.wy = (float)w[1]; o.wz = (float)w[2];
+    const M3 R = quat_to_matrix_scipy((double)(float)q[0], (double)(float)q[1], (double)(float)q[2], (double)(float)q[3]);
+    const double h = sqrt64(R.m21 * R.m21 + R.m22 * R.m22);
+    const double r = fast_atan2(R.m21, R.m22), pt = fast_atan2(-R.m20, h), y = fast_atan2(R.m10, R.m00);
+    o.roll = (float)r; o.pitch = (float)pt; o.yaw = (float)y;
+    o.r00 = (float)R.m00; o.r01 = (float)R.m01; o.r02 = (float)R.m02;
+    o.r10 = (float)R.m10; o.r11 = (float)R.m11; o.r12 = (float)R.m12;
+    o.r20 = (float)R.m20; o.r21 = (float)R.m21; o.r22 = (float)R.m22;
+    if (h > 1e-150) {
+        const double rh = rcp64(h);
+        double sr, cr, sp, cp, sy, cy;
+        rot_small(R.m21 * rh, R.m22 * rh, (double)o.roll - r, sr, cr);
+        rot_small(-R.m20, h, (double)o.pitch - pt, sp, cp);
+        rot_small(R.m10 * rh, R.m00 * rh, (double)o.yaw - y, sy, cy);
+        Re.m00 = cy * cp; Re.m01 = cy * sp * sr - sy * cr; Re.m02 = cy * sp * cr + sy * sr;
+        Re.m10 = sy * cp; Re.m11 = sy * sp * sr + cy * cr; Re.m12 = sy * sp * cr - cy * sr;
+        Re.m20 = -sp;     Re.m21 = cp * sr;                Re.m22 = cp * cr;
+    } else { // gimbal lock to the last bit: the angles are whatever atan2 makes of rounding noise; take them literally
+        Re = euler_to_matrix((double)o.roll, (double)o.pitch, (double)o.yaw);
+    }
+}
+
 // Reciprocals of per-launch constants, computed once on the host (a wave-uniform float64 division would
 // otherwise still cost every lane its ~12-instruction division sequence).
 struct Recips {

@@ -394,11 +394,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 __builtin_amdgcn_sched_barrier(0);
             }
             Observed ob;
-            observe<true, true>(p, q, v, w, ob);
+            M3 R; // from_euler(float32 euler read-back): only the PID modes use it
+            if (NEEDS_PID) observe_ctrl(p, q, v, w, ob, R); else observe<true, true>(p, q, v, w, ob);
             if (NEEDS_PID) {
                 float *g = wb.pid + la;
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
-                const M3 R = euler_to_matrix((double)ob.roll, (double)ob.pitch, (double)ob.yaw);
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
                     attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
