@@ -318,8 +318,9 @@ struct Pid {
 };
 
 // QuadControl.attitude_control (QuadControl.py:93-127).  Rt is the target rotation matrix.
+// nta = |ta| and rn = 1/|ta| come from the caller, which has them already (accel_control normalises ta).
 MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const M3 &Rt, const M3 &R, const Observed &o,
-                              V3 ta, double rpm[4])
+                              V3 ta, double nta, double rn, double rpm[4])
 {
     // E = Rt^T R - R^T Rt ; rot_e = (E21, E02, E10)   (:101-102)
     const double a21 = Rt.m02 * R.m01 + Rt.m12 * R.m11 + Rt.m22 * R.m21;
@@ -337,10 +338,8 @@ MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const
     const double tx = clampd(-(70000. * ex) + 0. * s.iox + 20000. * (0.0 - (double)o.wx), -3200., 3200.);
     const double ty = clampd(-(70000. * ey) + 0. * s.ioy + 20000. * (0.0 - (double)o.wy), -3200., 3200.);
     const double tz = clampd(-(60000. * ez) + 500. * s.ioz + 12000. * (0.0 - (double)o.wz), -3200., 3200.);
-    const double nta = norm(ta);
     double thrust = 0.;
     if (nta != 0) { // :117-122
-        const double rn = rcp64(nta);
         const double cosang = (ta.x * rn) * R.m02 + (ta.y * rn) * R.m12 + (ta.z * rn) * R.m22;
         thrust = rcp64(cosang > 0.2 ? cosang : 0.2) * nta * P.mass;
     }
@@ -357,7 +356,8 @@ MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in
                            double rpm[4])
 {
     const V3 ta = v3(ta_in.x + 0., ta_in.y + 0., ta_in.z + P.ctrl_gravity); // :76
-    const double rn = rsqrt64(dot(ta, ta));
+    const double d2 = dot(ta, ta);
+    const double rn = rsqrt64(d2);
     V3 tz = v3(ta.x * rn, ta.y * rn, ta.z * rn); // :78 (|ta| = 0 -> rsq = inf, 0 * inf = NaN -> next line)
     if (isnan(tz.x) || isnan(tz.y) || isnan(tz.z)) tz = v3(0., 0., 1.); // :79-80
     // :77 rotation is cast to float32; :82 x_t = R[:,1] x z_t (not normalised); :83 y_t = z_t x x_t
@@ -373,7 +373,7 @@ MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in
     Rt.m00 = tx.x * nx; Rt.m10 = tx.y * nx; Rt.m20 = tx.z * nx;
     Rt.m01 = ty.x * nx; Rt.m11 = ty.y * nx; Rt.m21 = ty.z * nx;
     Rt.m02 = tz.x; Rt.m12 = tz.y; Rt.m22 = tz.z;
-    attitude_control(P, K, s, Rt, R, o, ta, rpm);
+    attitude_control(P, K, s, Rt, R, o, ta, d2 > 0.0 ? d2 * rn : 0.0, rn, rpm);
 }
 
 // QuadControl.vel_control (QuadControl.py:51-70): vel_e and the derivative numerator are float32 arithmetic

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
-                    attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), rpm);
+                    attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), 9.81, 1.0 / 9.81, rpm);
                 } else {
                     if (ACT == MRS_ACT_TARGET_ACCEL) ta = v3((double)act[0], (double)act[1], (double)act[2]);
                     accel_control(P, A.rc, s, ta, R, ob, rpm);
