@@ -504,6 +504,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         __syncthreads();
         const int n = *ncontact; // uniform over the workgroup
         if (n > 0) {
+            // The solving wave is the workgroup's critical path (three waves wait for it at the barrier below) but
+            // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
+            // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
+            // priority lets it issue whenever it is ready.
+            __builtin_amdgcn_s_setprio(3);
             for (int sl = tid; sl < n; sl += BLOCK) {
                 const int b = clist[sl];
                 const double pp[3] = {0., 0., sp[2 * BLOCK + b]};
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 sp[7 * BLOCK + b] = vv[0]; sp[8 * BLOCK + b] = vv[1]; sp[9 * BLOCK + b] = vv[2];
                 sp[10 * BLOCK + b] = ww[0]; sp[11 * BLOCK + b] = ww[1]; sp[12 * BLOCK + b] = ww[2];
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
         p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
