@@ -187,6 +187,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
 #endif
+#ifndef MRS_TAIL_PRIO
+#define MRS_TAIL_PRIO 1
+#endif
 #ifndef MRS_FUSED_WAVES
 // the fused kernels are held to 128 VGPRs = 4 resident waves per SIMD = all 1024 workgroups of the bench swarm
 // resident at once (set_target_vel / _pos would take 132 / 134 uncapped and drop to 3: measured 43.2 vs 37.5 us)
@@ -522,6 +525,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
+        // waves past the contact barrier are nearer the end of the kernel than those still in the forces phase:
+        // letting them go first shortens the tail in which few waves are left per SIMD (measured 34.5 -> 33.8 us)
+        __builtin_amdgcn_s_setprio(MRS_TAIL_PRIO);
         p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
         q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
         v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
