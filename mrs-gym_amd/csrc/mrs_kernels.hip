@@ -187,8 +187,18 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
 #endif
-#ifndef MRS_TAIL_PRIO
-#define MRS_TAIL_PRIO 1
+// Wave priorities by phase, fused kernel: LAGGARDS FIRST.  The four waves of a SIMD do identical work; at equal
+// priority the arbiter lets the oldest run ahead, the waves finish one after another and the SIMD spends the
+// second half of the kernel with one or two waves left -- too few to hide latency (clock64 stamps: waves ended
+// between 42k and 79k ticks of a 79k-tick kernel).  Priority falling with progress (pair loop 2, controller 1,
+// pose/outputs 0) keeps them abreast: 34.3 -> 31.8 us per step.  The contact solve, the one serial stretch that
+// three waves of its workgroup wait for, runs at 3.
+#ifndef MRS_P_DW1
+#define MRS_P_DW1 2
+#define MRS_P_DW2 2
+#define MRS_P_CTRL 1
+#define MRS_P_TAIL 0
+#define MRS_P_ADJ 0
 #endif
 #ifndef MRS_FUSED_WAVES
 // the fused kernels are held to 128 VGPRs = 4 resident waves per SIMD = all 1024 workgroups of the bench swarm
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool doit = live && !masked && !env_nan;
     if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
+    if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_DW1);
     int my_slot = -1;
     bool parked = false;
     double downwash_acc = 0;
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
                     acc32 += f_self + f_in;
                     if ((k & 7) == 0) { downwash_acc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
+                    if (FUSED && k == 16 && MRS_P_DW2 != MRS_P_DW1) __builtin_amdgcn_s_setprio(MRS_P_DW2);
                 }
                 const float4 pj = nb[32];
                 const float dz = pj.z - mz;
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 }
             }
         }
+        if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_CTRL);
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
             double rpm[4];
@@ -525,9 +538,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
-        // waves past the contact barrier are nearer the end of the kernel than those still in the forces phase:
-        // letting them go first shortens the tail in which few waves are left per SIMD (measured 34.5 -> 33.8 us)
-        __builtin_amdgcn_s_setprio(MRS_TAIL_PRIO);
+        __builtin_amdgcn_s_setprio(MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
         p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
         q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
         v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
@@ -538,6 +549,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         }
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+        if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
         return;
     }
