@@ -238,12 +238,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (tid == 0) *ncontact = 0;
     if (n64) __syncthreads(); // counters visible before any wave runs ahead; taken here, before a load is in flight
     if (live) {
-        load_state(wb, la, T, p, q, v, w);
+        // Issue order = the order the data is needed in (loads return in order and the waits are counted): the
+        // action (NaN vote) and the position (LDS tile, pair loop) first, so that the quaternion and the velocities
+        // are still in flight while the pair loop runs instead of being waited for up front.
         if (ACT != MRS_ACT_NONE) {
             const float *ap = A.actions + (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N * ADIM;
 #pragma unroll
             for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
         }
+        load_state(wb, la, T, p, q, v, w);
     }
     if (n64) {
         lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
