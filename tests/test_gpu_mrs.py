@@ -366,3 +366,34 @@ def test_data_generation_loop_like_the_reference_example():
     ex = torch.stack(list(d["expert"]))
     assert torch.isfinite(ex).all() and float(ex.norm(dim=-1).max()) <= 1.0 + 1e-6
     assert torch.isfinite(torch.stack(list(d["X"]))).all()
+
+
+def test_bench_contract_single_and_two_ranks():
+    """bench.py end to end at a small size: one JSON line with the contract's keys for N=1, and the N>1 launch the
+    driver uses (torch.distributed.run, one rank per process) rehearsed with two gloo ranks sharing this one GPU:
+    weak scaling, per-step joint-observation all-gather reported beside `value`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRS_BENCH_PREWARM_S="0")
+    common = ["--steps", "20", "--warmup", "5", "--envs-per-gpu", "64"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline"] + common, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["unit"] == "agent-steps/s"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["config"]["workload"]
+    env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, env=env2, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0
+    assert d2["with_obs_allgather"]["value"] > 0 and d2["with_obs_allgather"]["bytes_sent_per_rank_per_step"] == 64 * 64 * 6 * 4
