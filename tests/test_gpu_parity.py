@@ -406,3 +406,31 @@ def test_full_size_bench_workload_properties():
     d = np.linalg.norm(p64[:, :, None, :] - p64[:, None, :, :], axis=-1)
     clear = np.abs(d - R) > 1e-4
     assert np.array_equal(bits[clear], ((d <= R) & ~np.eye(N, dtype=bool)[None])[clear])
+
+
+@pytest.mark.parametrize("N", [2, 63, 65, 129, 200, 257, 1000])
+def test_awkward_swarm_sizes_match_oracle(N):
+    """Workgroup tails (N not dividing 256), the LDS ring exchange for envs that span several waves (odd and even
+    N in (64, 256]) and the 1024-thread three-launch path, each through ground contact: 25 steps of three
+    ACTION_TYPEs from a low spawn, positions against the oracle and adjacency bit for bit."""
+    import mrsgym_amd
+    E = 5 if N < 300 else 2
+    pos, eul = grid_spawn(E, N, seed=N)
+    pos[..., 2] = 0.55 + 0.5 * (pos[..., 2] - 1.0)
+    z = np.zeros((E, N, 3), np.float32)
+    for atype in ("set_target_vel", "set_speeds", "set_control"):
+        sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+        sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+        sw = oracle.OracleSwarm(E, N)
+        sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z.astype(np.float64), angvel=z.astype(np.float64))
+        acts = ActionStream(atype, E, N, pos, seed=3, coherent=True)
+        obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+        dense = torch.zeros(E, N, N, device="cuda:0")
+        for t in range(25):
+            a = acts(t)
+            sh.step(torch.from_numpy(a).cuda(), atype, obs_out=obs, adj_out=adj, comm_range=2.0)
+            sw.step(a, atype)
+        assert np.abs(sh.view(sh.pos).cpu().numpy() - sw.pos).max() < 1e-6, atype
+        assert float(sh.pos[2].min()) < 0.58, "the run was meant to reach the contact zone"
+        sh.adjacency_expand(adj, dense)
+        assert np.array_equal(dense.cpu().numpy(), sw.adjacency(2.0)), atype
