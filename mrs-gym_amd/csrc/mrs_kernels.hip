@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -629,7 +630,19 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
     if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
 }
 
-// packed (M,N,W) -> dense float32 (M,N,N), one thread per output element (coalesced along j)
+// packed (M,N,W) -> dense float32 (M,N,N).  N % 4 == 0: one thread per four consecutive columns (a 16-byte store;
+// a wave writes 1 KB contiguous), grid-stride so that the launch stays a few thousand workgroups; otherwise one
+// thread per element.  Pure streaming: 4 N^2 bytes written per matrix.
+__global__ void k_adj_expand4(const uint64_t *__restrict__ packed, float4 *__restrict__ dense4, int N, int W, size_t total4)
+{
+    const int n4 = N >> 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = idx / n4;
+        const int j = (int)(idx - row * n4) << 2;
+        const unsigned nib = (unsigned)(packed[row * W + (j >> 6)] >> (j & 63)) & 15u; // j % 4 == 0: the four bits share a word
+        dense4[idx] = make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)(nib >> 3));
+    }
+}
 __global__ void k_adj_expand(const uint64_t *__restrict__ packed, float *__restrict__ dense, int N, int W, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1137,7 +1150,14 @@ extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float 
     const int block = 256;
     const size_t grid = (total + block - 1) / block;
     if (grid > 0x7fffffffull) return fail(MRS_E_ARG, "mrs_adjacency_expand: too large");
-    hipLaunchKernelGGL(k_adj_expand, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, packed, dense, h->N, h->W, total);
+    if ((h->N & 3) == 0 && ((uintptr_t)dense & 15) == 0) {
+        const size_t total4 = total >> 2;
+        const size_t g4 = (total4 + block - 1) / block;
+        hipLaunchKernelGGL(k_adj_expand4, dim3((unsigned)(g4 < 16384 ? g4 : 16384)), dim3(block), 0, (hipStream_t)stream, packed,
+                           reinterpret_cast<float4 *>(dense), h->N, h->W, total4);
+    } else {
+        hipLaunchKernelGGL(k_adj_expand, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, packed, dense, h->N, h->W, total);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_adjacency_expand launch");
 }
