@@ -43,7 +43,7 @@ def state_fn(quad):  # README.md:28-29
 
 
 def cpu_baseline(seconds=15.0):
-    """The CPU oracle (kind "port") on E=256 envs of the same workload, all host cores."""
+    """The CPU oracle (kind "port") on 32 envs per thread of the same workload: ~15 s of work on the host cores."""
     import oracle
     from util_scenarios import ActionStream, grid_spawn
     try:
@@ -66,7 +66,7 @@ def cpu_baseline(seconds=15.0):
         sw.step_full(a, ATYPE, COMM_RANGE)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > seconds or n >= 2000:
+        if dt > seconds or n >= 6000:
             break
     return {"value": E * N_AGENTS * n / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d agents x %d steps of the same workload (C oracle, OpenMP over envs, %.1f s)" % (E, N_AGENTS, n, dt)}
