@@ -235,9 +235,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
 
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
     float act[4] = {0, 0, 0, 0};
-    if (tid < A.epb) nanflag[tid] = 0;
-    if (tid == 0) *ncontact = 0;
-    if (n64) __syncthreads(); // counters visible before any wave runs ahead; taken here, before a load is in flight
+    if (tid < A.epb) nanflag[tid] = 0;    // N != 64: read after the tile barrier below
+    if (!FUSED) {                         // LDS slot counter of the three-launch path's compaction
+        if (tid == 0) *ncontact = 0;
+        if (n64) __syncthreads();         // visible before any wave runs ahead; taken here, before a load is in flight
+    }
     if (live) {
         // Issue order = the order the data is needed in (loads return in order and the waits are counted): the
         // action (NaN vote) and the position (LDS tile, pair loop) first, so that the quaternion and the velocities
@@ -514,23 +516,42 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // ---- contact: every lane stashes its state in LDS planes; the grounded bodies' lane ids are compacted
         // into clist and solved by the first ceil(n/64) waves reading/writing those planes.  Nothing but the
         // stash is live across the solve, so its registers and the controller's never coexist.
+        // Compaction without atomics or a zeroed counter: each wave ranks its own grounded lanes (ballot + mbcnt)
+        // into its own 64-entry segment of clist and publishes the count; the solver walks the segments in wave
+        // order, so the list -- and with it the order the bodies are solved in -- is the same on every run.
+        constexpr int NW = BLOCK / 64;
         int *clist = ncontact + 2;
         double *sp = reinterpret_cast<double *>(clist + BLOCK); // [13][BLOCK]
+        int *wcnt = reinterpret_cast<int *>(sp + 13 * BLOCK);   // [NW] per-wave counts
         sp[tid] = p[0]; sp[BLOCK + tid] = p[1]; sp[2 * BLOCK + tid] = p[2];
         sp[3 * BLOCK + tid] = q[0]; sp[4 * BLOCK + tid] = q[1]; sp[5 * BLOCK + tid] = q[2]; sp[6 * BLOCK + tid] = q[3];
         sp[7 * BLOCK + tid] = v[0]; sp[8 * BLOCK + tid] = v[1]; sp[9 * BLOCK + tid] = v[2];
         sp[10 * BLOCK + tid] = w[0]; sp[11 * BLOCK + tid] = w[1]; sp[12 * BLOCK + tid] = w[2];
-        if (parked) clist[atomicAdd(ncontact, 1)] = tid;
+        {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(parked);
+            const int lane = tid & 63;
+            if (parked) clist[(tid & ~63) + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = tid;
+            if (lane == 0) wcnt[tid >> 6] = __builtin_popcountll(m);
+        }
         __syncthreads();
-        const int n = *ncontact; // uniform over the workgroup
-        if (n > 0) {
+        int wend[NW]; // running end of each wave's segment in the concatenated list
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { n += wcnt[k]; wend[k] = n; }
+        if (n > 0) { // uniform over the workgroup
             // The solving wave is the workgroup's critical path (three waves wait for it at the barrier below) but
             // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
             // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
             // priority lets it issue whenever it is ready.
             __builtin_amdgcn_s_setprio(3);
             for (int sl = tid; sl < n; sl += BLOCK) {
-                const int b = clist[sl];
+                int seg = 0;
+#pragma unroll
+                for (int k = 0; k + 1 < NW; ++k) seg += (sl >= wend[k]);
+                int start = 0;
+#pragma unroll
+                for (int k = 0; k + 1 < NW; ++k) start = (seg == k + 1) ? wend[k] : start;
+                const int b = clist[seg * 64 + (sl - start)];
                 const double pp[3] = {0., 0., sp[2 * BLOCK + b]};
                 const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
                 double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
@@ -1058,8 +1079,8 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
     const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
-    // fused: + compacted lane list + 13 float64 state planes (36 872 B; 4 workgroups per CU fit the 160 KB LDS)
-    if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double), st, A);
+    // fused: + compacted lane list + 13 float64 state planes + per-wave counts (36 888 B; 4 workgroups per CU fit the 160 KB LDS)
+    if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
     else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, A);
     return hipGetLastError();
