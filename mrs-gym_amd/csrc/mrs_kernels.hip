@@ -223,6 +223,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool n64 = (BLOCK == 256) && (A.N == 64);
 
     const int tid = threadIdx.x;
+#ifdef MRS_TIMELINE // diagnostic build (tools/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
+                    // boundaries into the rpm buffer, 16 floats per wave, instead of the rotor speeds
+    const long long t_start = clock64();
+    float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
+#define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
     const int el = tid / A.N;
     const int i = tid - el * A.N;
     const int e = blockIdx.x * A.epb + el;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             env_nan = (el < A.epb) && nanflag[el];
         }
     }
+    TL(0); // loads, tile, NaN vote
     const bool masked = live && A.mask && !A.mask[e];
     const bool doit = live && !masked && !env_nan;
     if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
@@ -383,6 +392,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 }
             }
         }
+        TL(1); // pair loop
         if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_CTRL);
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
@@ -434,10 +444,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             } else {
                 rpm[0] = act[0]; rpm[1] = act[1]; rpm[2] = act[2]; rpm[3] = act[3];
             }
+#ifndef MRS_TIMELINE
             if (A.b.rpm) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) (wb.rpm + k * T)[la] = (float)rpm[k];
             }
+#endif
+            TL(2); // controller
             // ---- Quadcopter.set_speeds (Quadcopter.py:38-45): rotor thrusts + yaw reaction torque.
             // With ACTION_TYPE=set_speeds the reference's arithmetic is float32 (float32 action tensor).
             double F[4], sumw, zt;
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             fb.z += downwash_acc;
         }
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
+        TL(3); // forces + velocity integration
         if (FUSED) {
             parked = needs_contact(A.P, p[2]);
         } else if (needs_contact(A.P, p[2])) {
@@ -534,6 +548,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             if (lane == 0) wcnt[tid >> 6] = __builtin_popcountll(m);
         }
         __syncthreads();
+        TL(4); // barrier 1
         int wend[NW]; // running end of each wave's segment in the concatenated list
         int n = 0;
 #pragma unroll
@@ -561,8 +576,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 sp[10 * BLOCK + b] = ww[0]; sp[11 * BLOCK + b] = ww[1]; sp[12 * BLOCK + b] = ww[2];
             }
             __builtin_amdgcn_s_setprio(0);
+            TL(5); // own share of the contact solve
             __syncthreads();
         }
+        TL(6); // barrier 2
         __builtin_amdgcn_s_setprio(MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
         p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
         q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
@@ -573,9 +590,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             store_state(wb, la, T, p, q, v, w);
         }
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
+        TL(7); // pose + store
         if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        TL(8); // observation + adjacency
         return;
     }
     // Two-level compaction into one global list: lanes take slots from an LDS counter, ONE lane per
