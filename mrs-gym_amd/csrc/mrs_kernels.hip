@@ -934,6 +934,21 @@ static int hipfail(hipError_t e, const char *where)
     return (int)e;
 }
 
+// A handle is bound to one device (mrs_create); the caller's current device may be another one.  Every entry
+// point that launches selects the handle's device for the duration of the call and restores the caller's.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 extern "C" int mrs_abi_version(void) { return MRS_ABI_VERSION; }
 extern "C" const char *mrs_last_error(void) { return g_err; }
 
@@ -1035,6 +1050,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     if (!h->fused) { // the one-launch step keeps its contact list and parked states in LDS
         e = hipMalloc((void **)&h->ws, ws_bytes);
         if (e == hipSuccess) e = hipMemset(h->ws, 0, ws_bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
     if (e != hipSuccess) {
@@ -1109,6 +1125,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
                         const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream)
 {
     if (!h || !b) return fail(MRS_E_ARG, "mrs_step: NULL handle/buffers");
+    DeviceGuard dg(h->device);
     if (!b->pos || !b->quat || !b->vel || !b->angvel) return fail(MRS_E_ARG, "mrs_step: state buffers missing");
     if (action_type < MRS_ACT_NONE || action_type > MRS_ACT_TARGET_ORI)
         return fail(MRS_E_ACTION_TYPE, "mrs_step: unknown ACTION_TYPE (the reference raises AttributeError, Environment.py:92)");
@@ -1166,6 +1183,7 @@ static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)
 extern "C" int mrs_observe(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs_fields, void *stream)
 {
     if (!h || !b || !b->obs) return fail(MRS_E_ARG, "mrs_observe: NULL handle/buffers/obs");
+    DeviceGuard dg(h->device);
     StepArgs A;
     int rc = fill_common(h, b, obs_fields, n_obs_fields, NAN, A);
     if (rc) return rc;
@@ -1175,6 +1193,7 @@ extern "C" int mrs_observe(MrsHandle *h, const MrsBuffers *b, const int32_t *obs
 extern "C" int mrs_adjacency(MrsHandle *h, const MrsBuffers *b, double comm_range, void *stream)
 {
     if (!h || !b || !b->adj) return fail(MRS_E_ARG, "mrs_adjacency: NULL handle/buffers/adj");
+    DeviceGuard dg(h->device);
     if (std::isnan(comm_range)) return fail(MRS_E_ARG, "mrs_adjacency: comm_range is NaN");
     StepArgs A;
     int rc = fill_common(h, b, nullptr, 0, comm_range, A);
@@ -1185,6 +1204,7 @@ extern "C" int mrs_adjacency(MrsHandle *h, const MrsBuffers *b, double comm_rang
 extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int n_matrices, void *stream)
 {
     if (!h || !packed || !dense || n_matrices < 0) return fail(MRS_E_ARG, "mrs_adjacency_expand: bad argument");
+    DeviceGuard dg(h->device);
     const size_t total = (size_t)n_matrices * h->N * h->N;
     if (total == 0) return 0;
     const int block = 256;
@@ -1215,6 +1235,7 @@ extern "C" int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos
                              const float *vel, const float *angvel, const uint8_t *env_mask, void *stream)
 {
     if (!h || !b) return fail(MRS_E_ARG, "mrs_set_state: NULL handle/buffers");
+    DeviceGuard dg(h->device);
     if (ori && (ori_kind < MRS_ORI_EULER || ori_kind > MRS_ORI_MATRIX)) return fail(MRS_E_ARG, "mrs_set_state: bad ori_kind");
     SetArgs S;
     memset(&S, 0, sizeof(S));
@@ -1227,6 +1248,7 @@ extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double
                                  const double *vel, const double *angvel, const uint8_t *env_mask, void *stream)
 {
     if (!h || !b) return fail(MRS_E_ARG, "mrs_set_state_f64: NULL handle/buffers");
+    DeviceGuard dg(h->device);
     SetArgs S;
     memset(&S, 0, sizeof(S));
     S.b = *b; S.pos64 = pos; S.quat64 = quat; S.vel64 = vel; S.angvel64 = angvel; S.mask = env_mask;
@@ -1237,6 +1259,7 @@ extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double
 extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream)
 {
     if (!h || !b || !b->pid) return fail(MRS_E_ARG, "mrs_pid_reset: NULL handle/buffers");
+    DeviceGuard dg(h->device);
     const size_t T = (size_t)h->E * h->N;
     const int block = 256;
     hipLaunchKernelGGL(k_pid_reset, dim3((unsigned)((T + block - 1) / block)), dim3(block), 0, (hipStream_t)stream, *b, env_mask, h->N, T);
@@ -1247,6 +1270,7 @@ extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *e
 extern "C" int mrs_reynolds(MrsHandle *h, const float *x_prev, int D, float *actions, void *stream)
 {
     if (!h || !x_prev || !actions) return fail(MRS_E_ARG, "mrs_reynolds: NULL argument");
+    DeviceGuard dg(h->device);
     if (D < 6) return fail(MRS_E_ARG, "mrs_reynolds: D must be >= 6 (pos, vel lead the state vector)");
     const int grid = (h->E + h->epb - 1) / h->epb;
     const size_t lds = 2 * (size_t)h->block * sizeof(float4);
@@ -1260,6 +1284,7 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
                          const float ori_lo[3], const float ori_hi[3], int max_rounds, const uint8_t *env_mask, void *stream)
 {
     if (!h || !b || !ori_lo || !ori_hi) return fail(MRS_E_ARG, "mrs_spawn: NULL argument");
+    DeviceGuard dg(h->device);
     if (max_rounds < 1) return fail(MRS_E_ARG, "mrs_spawn: max_rounds must be >= 1");
     SpawnArgs S;
     memset(&S, 0, sizeof(S));

@@ -51,7 +51,15 @@ class ObsAllGather:
         self.done = [None] * buffers
 
     def gather(self, newest):
-        """Start gathering `newest` (contiguous (E_local,N,D)); returns the output buffer, complete after wait()."""
+        """Start gathering `newest` (contiguous (E_local,N,D)); returns the output buffer, complete after wait().
+
+        Ordering (GPU): the collective runs on a side stream behind an event recorded on the caller's stream NOW, so
+        it starts after the step kernel that wrote `newest` AND after everything the caller has enqueued so far --
+        including its reads of the output buffer this call is about to reuse.  Back-pressure: the caller's stream
+        first waits for the previous gather that used this buffer, so at most `buffers` gathers are ever in flight;
+        `newest` is a history-ring slot that the step kernel overwrites HISTORY_SLOTS - K steps later, so `buffers`
+        must stay below that (2 against >= K + 1 by construction of HistoryRing).  A consumer must call wait() (or
+        use its own wait_event on done[k]) before reading the returned buffer."""
         k = self.k
         self.k = (k + 1) % len(self.out)
         out = self.out[k]
@@ -59,8 +67,11 @@ class ObsAllGather:
             out.copy_(newest)
             return out
         if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            if self.done[k] is not None:
+                cur.wait_event(self.done[k])                             # back-pressure: gather t - buffers has landed
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))      # the step kernel that wrote `newest`
+            ready.record(cur)                                            # the step kernel that wrote `newest`
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
                 dist.all_gather_into_tensor(out, newest, group=self.group)

@@ -7,6 +7,8 @@ step kernel itself) or a vmapped tensor program -- never a Python loop over E*N 
 GUI / debug / sensor entry points (Environment.py:127-306, Object.py:100-195) are accepted and
 ignored: there is no GUI on a headless GPU env.
 """
+import warnings
+
 import torch
 
 from . import native
@@ -126,11 +128,8 @@ class Environment:
         """Object.get_ori: euler 'xyz' (roll,pitch,yaw) or 3x3 matrix of the float32-truncated quaternion."""
         sh = self._mrs.shard
         if not mat:
-            saved, n, d = sh.obs_codes, sh.n_obs, sh.D
-            sh.set_obs_fields(("ori",))
             out = torch.empty(sh.E, sh.N, 3, dtype=torch.float32, device=sh.device)
-            sh.observe(out)
-            sh.obs_codes, sh.n_obs, sh.D = saved, n, d
+            sh.observe(out, fields=("ori",))
             return self._out(out)
         q = sh.view(sh.quat).to(torch.float32).to(torch.float64)
         q = q / q.norm(dim=-1, keepdim=True)
@@ -230,7 +229,36 @@ class _VmapQuad:
         return self._idx
 
     def get_data(self, name):
-        return self.env.get_data(name)
+        # magent.py:35-37 style: quad.get_data("target_vel")[quad.get_idx(), :] -- under vmap the index is a batched
+        # 0-d tensor, which plain tensor indexing would .item(); hand out a view that indexes with index_select
+        val = self.env.get_data(name)
+        if isinstance(val, torch.Tensor) and val.dim() >= 1:
+            return _AgentIndexable(val, self._idx)
+        return val
+
+
+class _AgentIndexable:
+    """A tensor of env data that a vmapped state_fn may index with its own (batched) agent index."""
+
+    def __init__(self, t, idx):
+        self._t, self._idx = t, idx
+
+    def __getitem__(self, key):
+        first, rest = (key[0], key[1:]) if isinstance(key, tuple) else (key, ())
+        if first is self._idx:
+            row = torch.index_select(self._t, 0, first.reshape(1).to(self._t.device)).squeeze(0)
+            return row[rest] if rest else row
+        return self._t[key]
+
+    def __getattr__(self, name):
+        return getattr(self._t, name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        unwrap = lambda x: x._t if isinstance(x, _AgentIndexable) else x
+        args = tuple(unwrap(a) for a in args)
+        kwargs = {k: unwrap(v) for k, v in (kwargs or {}).items()}
+        return func(*args, **kwargs)
 
 
 class StateFnCompiler:
@@ -248,6 +276,7 @@ class StateFnCompiler:
         self.fused = False
         self.fields = None
         self._compiled = False
+        self._warned_loop = False
 
     def _recognise(self, fn):
         specs = []
@@ -301,10 +330,15 @@ class StateFnCompiler:
             return out if isinstance(out, torch.Tensor) else torch.as_tensor(out)
         try:
             X = torch.func.vmap(one)(pos, vel, ori, ang, idx)
-        except Exception:
+        except Exception as exc:
             if sh.E != 1:
                 raise
-            # single env: the reference's own per-agent loop (Environment.py:85-86)
+            # single env: the reference's own per-agent loop (Environment.py:85-86) -- correct but N Python calls
+            # per step; say so once instead of being quietly slow
+            if not self._warned_loop:
+                self._warned_loop = True
+                warnings.warn("state_fn cannot be batched with torch.func.vmap (%s: %s); falling back to the per-agent "
+                              "Python loop of the reference (Environment.py:85-86)" % (type(exc).__name__, exc), RuntimeWarning)
             X = torch.stack([torch.as_tensor(fn(a)) for a in env.agents], dim=0)
         X = X.to(torch.float32).reshape(sh.E, sh.N, -1)
         return X[0] if sh.E == 1 else X

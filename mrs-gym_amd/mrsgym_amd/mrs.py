@@ -9,6 +9,7 @@ gains a leading E axis: Xk (E,K+1,N,D), Ak (E,K+1,N,N), actions (E,N,ACTION_DIM)
 import math
 import time
 import types
+import warnings
 
 import numpy as np
 import torch
@@ -283,7 +284,8 @@ class MRS(_EnvBase):
         else:
             lo, hi = so[:3].tolist(), so[3:].tolist()
         self._resets += 1
-        self.shard.status.zero_()
+        # only the spawn bit: a pending NaN-action flag must survive until check_errors() has raised it
+        self.shard.status.bitwise_and_(~native.STATUS_SPAWN_FAIL)
         self.shard.spawn(seed=(int(self.SEED) << 20) + self._resets, env_index_base=self.ENV_INDEX_BASE,
                          agent_radius=self.AGENT_RADIUS, ori_lo=lo, ori_hi=hi, env_mask=env_mask)
         if int((self.shard.status & native.STATUS_SPAWN_FAIL).any()):
@@ -294,6 +296,8 @@ class MRS(_EnvBase):
 
     # ------------------------------------------------------------------ Gym API
     def reset(self, pos=None, ori=None, vel=None, angvel=None):  # MRS.py:174-192
+        if self.is_initialised:
+            self.check_errors()      # a NaN action flagged since the last poll raises here, not never (MRS.py:247-248)
         self.is_initialised = True
         E, N = self.N_ENVS, self.N_AGENTS
         spawned = False
@@ -335,6 +339,7 @@ class MRS(_EnvBase):
         history are written through env masks on the device.  Returns the stacked Xk of all envs."""
         if not self.is_initialised:
             raise RuntimeError("reset_envs() before reset()")
+        self.check_errors()
         E, N = self.N_ENVS, self.N_AGENTS
         mask = torch.as_tensor(env_mask, device=self.device).to(torch.bool).reshape(E)
         spawned = False
@@ -390,14 +395,14 @@ class MRS(_EnvBase):
     def get_data(self, name):
         return self.env.get_data(name)
 
-    def __del__(self):
-        self.close()
+    def __del__(self):   # no device work in a finaliser (check_errors() synchronises); close() is the explicit form
+        pass
 
     def close(self):  # MRS.py:220-224: never raises
         try:
             self.check_errors()
-        except Exception:
-            pass
+        except Exception as exc:   # an unreported NaN action (lazy CHECK_NAN): the reference would have raised in step()
+            warnings.warn("MRS.close(): %s" % (exc,), RuntimeWarning)
 
     def render(self, mode='bullet', close=False):  # MRS.py:227-229
         if close:
@@ -458,7 +463,7 @@ class MRS(_EnvBase):
             self._expand_newest_A()
             Ak = self.get_Ak()
         mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
-        if mode == "lazy" and (self.steps_since_reset & 255) == 255:
+        if mode == "lazy" and (self._global_step & 255) == 255:   # _global_step: never zeroed by reset()
             self.check_errors()
         # update function; draw_links is a GUI-only no-op here (MRS.py:259)
         kw = dict(env=self.env, X=Xk, A=Ak, action=self.last_action, steps_since_reset=self.steps_since_reset)

@@ -271,9 +271,14 @@ class SwarmShard:
         if rc:
             _check(rc, "mrs_step")
 
-    def observe(self, obs_out):
+    def observe(self, obs_out, fields=None):
+        """Newest observation slice of the current state; `fields` overrides the shard's fused spec for this call only."""
         b = self._buffers(obs_out, None)
-        _check(self.L.mrs_observe(self.h, C.byref(b), self.obs_codes, self.n_obs, _stream(self.device)), "mrs_observe")
+        codes, n = self.obs_codes, self.n_obs
+        if fields is not None:
+            lst = [OBS[f] if isinstance(f, str) else int(f) for f in fields]
+            codes, n = (C.c_int32 * max(1, len(lst)))(*lst), len(lst)
+        _check(self.L.mrs_observe(self.h, C.byref(b), codes, n, _stream(self.device)), "mrs_observe")
 
     def adjacency(self, adj_out, comm_range):
         b = self._buffers(None, adj_out)

@@ -1,0 +1,161 @@
+"""The reference-generated golden vectors F1 (QuadControl cascade) and F2 (nnlsRPM) replayed on the GPU through
+the C-ABI (mrs_set_state + mrs_step, rotor speeds read back from MrsBuffers.rpm).
+
+These are the controller / mixer branches whose device code has no line-for-line counterpart in the oracle:
+the closed-form 2+2 NNLS split (mrs_device.hpp nnls2), the small-angle reconstruction of from_euler(float32
+euler) and the bounded-range trig, incl. the large-attitude quarter of F1 (roll/pitch up to 1.2 rad, yaw +-pi).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _shard(E, N, fields=("pos", "vel")):
+    import mrsgym_amd
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", obs_fields=fields, want_rpm=True)
+    p = mrsgym_amd.default_params()
+    p.enable_contact = 0
+    p.ground_z = -1e9            # only the rotor speeds are looked at; keep the ground out of it
+    sh.set_params(p)
+    return sh
+
+
+# ---------------------------------------------------------------------------------------------- F2
+# SURVEY.md 8c anchors of Quadcopter.nnlsRPM (Quadcopter.py:172-208): two-zero, single-active-variable and the
+# all-zero KKT case (negative thrust: every component of A^T B is <= 0)
+ANCHORS = [((0.027 * 9.81, 0, 0, 0), [14475.80915296] * 4),
+           ((0.027, 1.4e-5, 0, 0), [4664.2590609, 4664.2590609, 4578.88702636, 4578.88702636]),
+           ((0.027, 3e-3, 0, 0), [9211.17475125, 9211.17475125, 0, 0]),
+           ((0.1, 0, -5e-3, 1e-4), [13972.41181714, 0, 0, 14269.7090935]),
+           ((0, 1e-3, 1e-3, 0), [0, 6129.96615759, 0, 0]),
+           ((-0.05, 0, 0, 0), [0, 0, 0, 0]),
+           ((-0.05, 1e-4, -1e-4, 1e-5), None),        # oracle only
+           ((0.0, 0, 0, 0), [0, 0, 0, 0])]
+
+
+def test_F2_nnls_branch_on_gpu(golden_dir):
+    """mrs_step<set_control> with control = wrench / (Mass, Ixx, Iyy, Izz) (Quadcopter.py:26-34): the kernel's
+    float32 product restores the wrench to 6e-8 relative, so
+      * against the oracle fed the SAME float32 control (orc_set_control: literal Lawson-Hanson): rpm^2 to 1e-9
+        of the wrench scale -- the closed-form nnls2 split vs the iterative active-set solve;
+      * against the reference's own F2 rpm: rpm^2 to 1e-6 of the scale (the float32 input rounding), and the same
+        branch taken (an NNLS solution has a rotor at exactly 0) except for wrenches within that rounding of the
+        branch condition min(Ainv B) = 0."""
+    d = np.load(os.path.join(golden_dir, "F2_nnls.npz"))
+    w = np.concatenate([d["wrench"], np.array([a for a, _ in ANCHORS], np.float64)])
+    want = np.concatenate([d["rpm"], np.array([r if r is not None else [np.nan] * 4 for _, r in ANCHORS])])
+    branch = np.concatenate([d["nnls_branch"], np.zeros(len(ANCHORS), bool)])
+    n_fix = len(d["wrench"])
+    assert branch[:n_fix].mean() > 0.4                    # at least 40 % of the fixture is on the NNLS branch
+    p = oracle.default_params()
+    k = np.array([p.mass, p.ixx_file, p.iyy_file, p.izz_file])
+    ctrl = (w / k).astype(np.float32)
+    n = len(w)
+    N = 64
+    E = (n + N - 1) // N
+    pad = np.zeros((E * N, 4), np.float32)
+    pad[:n] = ctrl
+    pad[n:] = [9.81, 0, 0, 0]
+    sh = _shard(E, N)
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8)), -1).reshape(-1, 2).astype(np.float32)
+    pos = np.concatenate([np.broadcast_to(g, (E, N, 2)), np.full((E, N, 1), 5.0, np.float32)], -1)
+    sh.set_state(pos=pos, ori=np.zeros((E, N, 3), np.float32), vel=np.zeros((E, N, 3), np.float32), angvel=np.zeros((E, N, 3), np.float32))
+    sh.step(torch.from_numpy(pad.reshape(E, N, 4)).cuda(), "set_control")
+    torch.cuda.synchronize()
+    rpm = sh.view(sh.rpm).cpu().numpy().reshape(E * N, 4)[:n].astype(np.float64)     # float32 read-back of the float64 rpm
+    assert np.isfinite(rpm).all()
+    bc = np.array([1 / p.kf, 1 / (p.kf * p.arm), 1 / (p.kf * p.arm), 1 / p.km])
+    w32 = (ctrl * k.astype(np.float32)).astype(np.float64)      # the wrench the kernel (and the oracle) actually see
+    scale = np.abs(w32 * bc).max(1) + 1.0                        # size of B: rpm^2 lives on this scale
+    orc = np.stack([oracle.set_control(c) for c in ctrl])
+    # float32 storage of rpm: 6e-8 relative on rpm -> 1.2e-7 on rpm^2
+    assert (np.abs(rpm ** 2 - orc ** 2) / scale[:, None]).max() < 3e-7, "GPU nnls2 vs the oracle's Lawson-Hanson"
+    # active sets: a rotor the solve puts at 0 (exact cancellations such as thrust = 0 come out as +-1e-16 of the scale
+    # under the device's contracted a*b+c; sqrt() of that is not 0.0 but is zero on the scale of the problem)
+    zero = lambda r: r ** 2 < 1e-9 * scale[:, None]
+    assert np.array_equal(zero(rpm), orc == 0), "active sets differ from the oracle's"
+    fin = ~np.isnan(want).any(1)
+    assert (np.abs(rpm[fin] ** 2 - want[fin] ** 2) / scale[fin][:, None]).max() < 2e-6, "GPU vs the reference's nnlsRPM"
+    # the branch itself: the reference took scipy.optimize.nnls for exactly these rows
+    c = 1 / np.sqrt(2)
+    A = np.array([[1, 1, 1, 1], [c, c, -c, -c], [-c, c, c, -c], [-1, 1, -1, 1]])
+    sq = (np.linalg.inv(A) @ (w[:n_fix] * bc).T).T
+    clear = np.abs(sq.min(1)) > 1e-5 * scale[:n_fix]            # away from the branch condition
+    got_branch = zero(rpm)[:n_fix].any(1)
+    assert clear.mean() > 0.95
+    assert np.array_equal(got_branch[clear], branch[:n_fix][clear])
+    assert got_branch.sum() >= 200                               # the NNLS code really ran on the device
+    # anchors, as rpm (they are far from the sqrt singularity at 0 or exactly 0)
+    for i, (a, r) in enumerate(ANCHORS):
+        if r is not None:
+            np.testing.assert_allclose(rpm[n_fix + i], r, rtol=3e-7, atol=1e-3, err_msg=str(a))
+
+
+# ---------------------------------------------------------------------------------------------- F1
+MODES = {"pos": "set_target_pos", "vel": "set_target_vel", "accel": "set_target_accel", "ori": "set_target_ori"}
+
+
+@pytest.mark.parametrize("mode", ["pos", "vel", "accel", "ori"])
+def test_F1_quadcontrol_cascade_on_gpu(golden_dir, mode):
+    """Every F1 tuple is one quadcopter: set_state(pos, euler, vel, angvel) -> mrs_step<set_target_*> -> rpm, five
+    consecutive calls (the PID planes persist across set_state, like the reference's QuadControl object).
+    What the device controller sees is the float32 read-back of the float64 state (Object.py:78-97): the euler
+    angles come back through quaternion -> float32 -> matrix -> atan2, 1e-7 away from the fixture's; therefore
+      * against the oracle controller fed the euler angles the GPU itself reports (mrs_observe): 2e-6 relative
+        (float32 storage of rpm) -- this is the check of the device arithmetic, all attitudes;
+      * against the reference's F1 rpm: 0.05 rpm absolute (4e-6 of hover) -- the read-back noise times the
+        attitude gain 0.2685 * 7e4 per rad."""
+    d = np.load(os.path.join(golden_dir, "F1_quadcontrol.npz"))
+    modes = [str(x) for x in d["modes"]]
+    m = modes.index(mode)
+    n, calls = d["rpm"].shape[1], d["rpm"].shape[2]
+    N = 64
+    E = n // N
+    assert E * N == n
+    large = (np.arange(n) % 4 == 0)                      # gen_golden: a quarter of the cases at large attitude
+    assert np.abs(d["ori"][large][..., :2]).max() > 1.0
+    sh = _shard(E, N, fields=("pos", "ori", "vel", "angvel"))
+    ctl = [oracle.Controller() for _ in range(n)]
+    obs = torch.zeros(E, N, 12, device="cuda:0")
+    worst_ref, worst_orc = 0.0, 0.0
+    for c in range(calls):
+        a = {x: d[x][:, c] for x in ("pos", "vel", "ori", "angvel", "target")}
+        sh.set_state(pos=a["pos"].reshape(E, N, 3), ori=a["ori"].reshape(E, N, 3), vel=a["vel"].reshape(E, N, 3),
+                     angvel=a["angvel"].reshape(E, N, 3))
+        sh.observe(obs)
+        o = obs.cpu().numpy().reshape(n, 12)
+        seen = dict(pos=o[:, 0:3], ori=o[:, 3:6], vel=o[:, 6:9], angvel=o[:, 9:12])
+        assert np.array_equal(seen["pos"], a["pos"]) and np.array_equal(seen["vel"], a["vel"]) and np.array_equal(seen["angvel"], a["angvel"])
+        # same rotation: euler angles agree to the float32 quaternion's resolution (compare as rotations: yaw +-pi wraps)
+        dang = np.abs((seen["ori"] - a["ori"] + np.pi) % (2 * np.pi) - np.pi)
+        assert dang.max() < 5e-6, dang.max()
+        act = a["target"] * np.float32(0.3) if mode == "ori" else a["target"]
+        sh.step(torch.from_numpy(np.ascontiguousarray(act.reshape(E, N, 3))).cuda(), MODES[mode])
+        torch.cuda.synchronize()
+        rpm = sh.view(sh.rpm).cpu().numpy().reshape(n, 4).astype(np.float64)
+        want = d["rpm"][m, :, c]
+        orc = np.zeros((n, 4))
+        for i in range(n):
+            if mode == "pos":
+                orc[i] = ctl[i].pos_control(seen["pos"][i], seen["vel"][i], seen["ori"][i], seen["angvel"][i], a["target"][i])
+            elif mode == "vel":
+                orc[i] = ctl[i].vel_control(seen["vel"][i], seen["ori"][i], seen["angvel"][i], a["target"][i])
+            elif mode == "accel":
+                orc[i] = ctl[i].accel_control(a["target"][i].astype(np.float64), seen["ori"][i], seen["angvel"][i])
+            else:
+                orc[i] = ctl[i].attitude_control(act[i].astype(np.float64), seen["ori"][i], seen["angvel"][i])
+        worst_orc = max(worst_orc, (np.abs(rpm - orc) / np.abs(orc)).max())
+        worst_ref = max(worst_ref, np.abs(rpm - want).max())
+        np.testing.assert_allclose(rpm, orc, rtol=2e-6, atol=0, err_msg="%s call %d vs oracle on the GPU's own read-back" % (mode, c))
+        np.testing.assert_allclose(rpm, want, rtol=0, atol=0.05, err_msg="%s call %d vs the reference's F1" % (mode, c))
+        # not everything sits on the pwm clip rails [9440.3, 21666.4] (QuadControl.py:125); vel mode does from its
+        # second call on (the derivative term divides a random jump by DT)
+        assert ((want > 9441) & (want < 21666)).mean() > (0.5 if mode != "vel" or c == 0 else -1)
+    print("F1 on the GPU,", mode, ": max |rpm - F1| = %.2e rpm, max rel vs oracle = %.1e" % (worst_ref, worst_orc))

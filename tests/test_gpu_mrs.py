@@ -144,6 +144,60 @@ def test_callbacks_and_quirks():
     assert env.get_env().draw_links(None) is None and env.get_env().set_colour(q, [1, 0, 0]) is None
 
 
+def test_lazy_nan_action_is_raised_even_with_short_episodes():
+    """CHECK_NAN="lazy" (the default for N_ENVS > 1): a NaN action is flagged on the device, the env does not step
+    (MRS.py:247-248) and the exception surfaces at the next poll -- which must not depend on episodes being
+    longer than the poll period, nor be wiped by reset()'s spawn (episodes of 50 steps here)."""
+    import mrsgym_amd
+    E, N = 4, 6
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, SEED=5)
+    raised_at = None
+    a = torch.zeros(E, N, 3, device="cuda")
+    try:
+        for t in range(600):
+            if t % 50 == 0 and t > 0:
+                env.reset()
+            act = a.clone()
+            if t == 3:
+                act[2, 1, 0] = float("nan")
+            env.step(act)
+    except Exception as exc:
+        raised_at = t
+        assert "NaN" in str(exc) and "[2]" in str(exc)
+    assert raised_at is not None and raised_at <= 50      # the reset() after the first episode at the latest
+    # ... and the flag is consumed: the loop can go on
+    env.reset()
+    for t in range(5):
+        env.step(a)
+    env.check_errors()
+
+
+def test_generic_state_fn_is_vmapped_across_envs():
+    """A state_fn the recogniser cannot fuse (arithmetic on the getters, per-agent data), N_ENVS > 1: evaluated for all
+    E*N quadcopters at once with torch.func.vmap -- same numbers as the per-agent formula on the batched getters."""
+    import mrsgym_amd
+    E, N = 5, 7
+    pos, eul = grid_spawn(E, N, seed=6)
+
+    def fn(quad):
+        gain = quad.get_data("gain")[quad.get_idx()]
+        return torch.cat([quad.get_pos() * 2.0 - quad.get_vel(), quad.get_ori()[2:3] * gain, quad.get_angvel().norm().reshape(1)])
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=fn, K_HOPS=1, COMM_RANGE=2.0,
+                          START_POS=torch.from_numpy(pos), start_fn=lambda m: m.set_data("gain", torch.arange(1., N + 1, device=m.device)))
+    assert not env._obs.fused
+    X = env.reset(ori=torch.from_numpy(eul))
+    assert X.shape == (E, 2, N, 5)
+    acts = ActionStream("set_target_vel", E, N, pos, seed=2)
+    for t in range(12):
+        X, r, d, info = env.step(torch.from_numpy(acts(t)))
+    w = env.get_env()
+    gain = torch.arange(1., N + 1, device="cuda")
+    want = torch.cat([w.get_pos() * 2.0 - w.get_vel(), w.get_ori()[..., 2:3] * gain[None, :, None],
+                      w.get_angvel().norm(dim=-1, keepdim=True)], -1)
+    assert torch.allclose(X[:, 0], want, rtol=0, atol=1e-6)
+    assert float(X[:, 0, :, 4].abs().max()) > 0
+
+
 F6 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F6_step_N*.npz")))
 
 

@@ -112,6 +112,10 @@ def test_F6_reference_step_teacher_forced(path):
     N, atype = int(name.split("_")[0][1:]), name.split("_", 1)[1]
     sw = _swarm(d, N)
     K, D = int(d["K_HOPS"]), int(d["D"])
+    if atype == "set_control":
+        # the fixture really enters the NNLS branch of nnlsRPM (Quadcopter.py:204-207): an NNLS solution has a rotor at 0
+        nnls = sum(int((oracle.set_control(a) == 0).any()) for a in d["actions"].reshape(-1, 4))
+        assert nnls >= 0.3 * d["actions"].shape[0] * N, nnls
     for t in range(d["actions"].shape[0]):
         sw.step(d["actions"][t], atype)
         w, wr = sw.wrench[0], d["wrench"][t]

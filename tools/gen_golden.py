@@ -372,6 +372,8 @@ def gen_F6(out):
                 if hi < N:
                     start[lo, 2] = rng.uniform(1.0, 1.5)
                     start[hi] = start[lo] + np.array([rng.uniform(-.05, .05), rng.uniform(-.05, .05), rng.uniform(0.9, 1.2)])
+            if atype == "set_control":
+                start[:, 2] += 2.5                  # open loop with free-fall blocks: keep it off the ground for a while
             start = start.astype(np.float32)
             ori0 = np.concatenate([rng.uniform(-.1, .1, (N, 2)), rng.uniform(-np.pi / 2, np.pi / 2, (N, 1))], 1).astype(np.float32)
             fake.__init__()
@@ -396,8 +398,15 @@ def gen_F6(out):
                 elif atype == "set_control":
                     if t % 20 == 0:
                         act = np.concatenate([9.81 + rng.uniform(-1, 1, (N, 1)), rng.uniform(-1, 1, (N, 3))], 1)
+                        # Quadcopter.py:204: scipy's nnls runs iff min(Ainv B) < 0, i.e. iff the torque terms
+                        # 0.354 (|B1| + |B2|) + 0.25 |B3| (~7e5 per unit of |control|) exceed 0.25 B0 = 2.1e7 * a_thrust.
+                        # Every other block: thrust 0.2..0.6 m/s^2 and torques x20 => most quadcopters take the NNLS
+                        # branch (asserted in tests: nnls_branch); the block after it thrusts 2 g minus that to recover.
                         if t % 40 == 0:
-                            act[:, 1:] *= 40.0          # large torques => NNLS branch
+                            act[:, 0] = 0.4 + 0.2 * (act[:, 0] - 9.81)
+                            act[:, 1:] *= 20.0
+                        else:
+                            act[:, 0] += 9.81 - 0.4
                 else:
                     act = hover * (1 + 0.05 * rng.uniform(-1, 1, (N, 4)))
                 a32 = torch.tensor(act, dtype=torch.float32)
