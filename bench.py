@@ -10,9 +10,13 @@ cat(pos, vel); synthetic swarm of SURVEY.md 8d (grid spawn, per-agent U[-1,1]^3 
 steps, pre-generated on the device).  One "step" = one env.step(actions) of the product API over the
 whole batch: fused controller + rotor/aero forces + downwash + 6-DoF integration + ground contact +
 newest observation slice + bit-packed newest adjacency rows, written into the K_HOPS history ring.
-Weak scaling: every GPU owns 4096 envs and step() has no exchange between them, so `value` times the
-sharded path alone; with N>1 the same K steps are then repeated with the joint observation tensor
-all-gathered over RCCL every step (side stream, double-buffered) and reported as `with_obs_allgather`.
+Before anything is timed the swarm is rolled in for ROLLIN untimed steps (default 700, key `rollin_steps`) to
+the workload's steady state -- a part of the swarm on the ground -- so that a short run (--steps 20) times the
+same regime as a long one and as the rocprofv3 summaries under profiles/.
+Weak scaling: every GPU owns 4096 envs.  N = 1: `value` is the sharded path itself.  N > 1: `value` is BASELINE
+config 5's definition -- every step is followed by the RCCL all-gather of the joint observation tensor (side
+stream, double-buffered, back-pressured); the same K steps without the exchange are reported beside it as
+`no_exchange`, with the xGMI floor of the gather.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM (algorithmic bytes,
 SURVEY.md 8d: 268 B per agent-step at this config); `cpu_baseline` times the CPU oracle (a C port of
@@ -78,6 +82,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--rollin", type=int, default=int(os.environ.get("MRS_BENCH_ROLLIN", "700")),
+                    help="untimed steps before the warm-up: brings the swarm to the workload's steady state")
+    ap.add_argument("--no-dense-a", action="store_true", help="skip the extra dense-adjacency leg (N=1)")
     ap.add_argument("--dense-a", action="store_true", help="materialise the float32 (E,K+1,N,N) adjacency the reference returns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -100,52 +107,54 @@ def main():
     base = rank * E
     pos, eul = grid_spawn(E, N, env_base=base)
 
-    def make_env():
+    def make_env(a_format):
         env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
                               RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos),
-                              A_FORMAT="dense" if args.dense_a else "packed", ENV_INDEX_BASE=base, DEVICE=str(dev),
-                              CHECK_NAN="lazy")
+                              A_FORMAT=a_format, ENV_INDEX_BASE=base, DEVICE=str(dev), CHECK_NAN="lazy")
         env.reset(ori=torch.from_numpy(eul))
         return env
 
     acts = ActionStream(ATYPE, E, N, pos, seed=1000 + rank)
     total = args.warmup + args.steps
-    table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range((2 * total if world > 1 else total) // 50 + 1)]
-    # Process/device warm-up on a SCRATCH swarm, before the W warm-up steps of the measured one: the first
-    # ~0.1 s of launches of a fresh process run ~20 % slow (62 vs 52 us/step measured; clock ramp + the HIP
-    # runtime growing its signal/kernarg pools), and on a fresh box the first process is slower still.  The
-    # measured swarm then starts from its spawn state exactly as the workload definition says.
+    n_regions = 2 if (world > 1 or not args.no_dense_a) else 1
+    table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range((args.rollin + n_regions * total) // 50 + 2)]
+    # Process/device warm-up on a SCRATCH swarm, before anything measured: the first ~0.1 s of launches of a fresh
+    # process run ~20 % slow (62 vs 52 us/step measured; clock ramp + the HIP runtime growing its signal/kernarg
+    # pools), and on a fresh box the first process is slower still.
     prewarm_s = float(os.environ.get("MRS_BENCH_PREWARM_S", "1.0"))
     if prewarm_s > 0:
-        scratch = make_env()
+        scratch = make_env("packed")
         t_end = time.perf_counter() + prewarm_s
         while time.perf_counter() < t_end:
             for t in range(500):
                 scratch.step(table[0])
             torch.cuda.synchronize()
         del scratch
-    env = make_env()
-    assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
     gather = mdist.ObsAllGather(E, N, 6, dev) if world > 1 else None
-
-    def one_step(t, with_gather):
-        X, r, d, info = env.step(table[(t // 50) % len(table)])
-        if with_gather:
-            gather.gather(env._Xring.newest())
-        return X, info
-
     # HIP events on the stream the step kernels are launched on (torch's current stream) bracket SPANS of
     # EV_SPAN consecutive mrs_step launches, one span every EV_EVERY steps: on this stack a timing-event pair
     # costs the stream ~60 us (measured 137 us per step with a pair on every step against 76 us with none),
     # so the per-launch duration is sampled and the pair's cost amortised over the span.
     EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
     EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "10")), EV_EVERY, args.steps))
-    shard_step = env.shard.step_ptr
 
-    def timed_region(t_first, with_gather):
+    def rollin(env):
+        """ROLLIN untimed steps from the spawn state: the workload's steady state (a part of the swarm grounded)."""
+        for t in range(args.rollin):
+            env.step(table[t // 50])
+        torch.cuda.synchronize()
+        return float((env.shard.pos[2] < 0.6).float().mean())
+
+    def timed_region(env, t_first, with_gather):
         """W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier; max over ranks."""
+        shard_step = env.shard.step_ptr
+
+        def one_step(t):
+            env.step(table[t // 50])
+            if with_gather:
+                gather.gather(env._Xring.newest())
         for t in range(t_first, t_first + args.warmup):
-            one_step(t, with_gather)
+            one_step(t)
         if with_gather:
             gather.wait()
         torch.cuda.synchronize()
@@ -168,7 +177,7 @@ def main():
         env.shard.step_ptr = timed_step
         t0 = time.perf_counter()
         for t in range(t_first + args.warmup, t_first + total):
-            one_step(t, with_gather)
+            one_step(t)
         host_elapsed = time.perf_counter() - t0     # launch loop only: equals `elapsed` when the host is the limit
         if with_gather:
             gather.wait()
@@ -186,49 +195,78 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, host_elapsed, kernel_ms
 
-    # `value`: the sharded path itself -- envs are independent, so step() has no exchange and none is timed.
-    elapsed, host_elapsed, kernel_ms = timed_region(0, False)
-    # N > 1, reported beside it: the same K steps with the joint observation tensor all-gathered over RCCL every
-    # step (side stream, double-buffered), for consumers that want every rank to hold all of X.
-    gathered = None
-    if world > 1 and os.environ.get("MRS_BENCH_OBS_ALLGATHER", "1") == "1":
-        g_elapsed, _, _ = timed_region(total, True)
-        gathered = {"value": float(E) * N * args.steps * world / g_elapsed, "unit": "agent-steps/s",
-                    "ms_per_step": g_elapsed / args.steps * 1e3,
-                    "bytes_sent_per_rank_per_step": E * N * 6 * 4 * (world - 1),
-                    "what": "newest observation slice (E_local,N,6) float32 all-gathered to every rank each step (RCCL)"}
+    env = make_env("dense" if args.dense_a else "packed")
+    assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
+    grounded = rollin(env)
+    agent_steps = float(E) * N * args.steps * world
+    extra = {}
+    if world == 1:
+        # `value`: the step itself -- one GPU, nothing to exchange
+        elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, False)
+        if not args.no_dense_a and not args.dense_a:
+            # the reference's return format: float32 0/1 (E,K+1,N,N) adjacency materialised every step (a second launch)
+            del env
+            denv = make_env("dense")
+            rollin(denv)
+            d_elapsed, _, _ = timed_region(denv, args.rollin, False)
+            extra["dense_a"] = {"value": agent_steps / d_elapsed, "unit": "agent-steps/s", "ms_per_step": d_elapsed / args.steps * 1e3,
+                                "what": "same K steps with info['A'] as the dense float32 (E,K+1,N,N) tensor the reference returns "
+                                        "(516 B per agent-step algorithmic, SURVEY.md 8d) instead of bit-packed rows"}
+    else:
+        # `value`: BASELINE config 5 / north_star -- every step followed by the RCCL all-gather of the joint observation
+        elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, True)
+        n_elapsed, _, _ = timed_region(env, args.rollin + total, False)
+        per_rank = E * N * 6 * 4
+        extra["no_exchange"] = {"value": agent_steps / n_elapsed, "unit": "agent-steps/s", "ms_per_step": n_elapsed / args.steps * 1e3,
+                                "what": "the same K steps without the all-gather: step() itself has no exchange between shards"}
+        extra["obs_allgather"] = {"bytes_sent_per_rank_per_step": per_rank * (world - 1), "bytes_received_per_rank_per_step": per_rank * (world - 1),
+                                  "xgmi_floor_ms": per_rank * (world - 1) / (min(world - 1, 7) * 76e9) * 1e3,
+                                  "what": "newest observation slice (E_local,N,6) float32 to every rank each step (RCCL, side stream, "
+                                          "double-buffered); floor = bytes received / (links driven x ~76 GB/s per xGMI link direction)"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    agent_steps = float(E) * N * args.steps * world
     value = agent_steps / elapsed
     algo_bytes_launch = ALGO_BYTES_PER_AGENT_STEP * E * N
     achieved = algo_bytes_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes (see profiles/README.md)
-    if os.path.exists(tp) and E == ENVS_PER_GPU and not args.dense_a:   # counters were collected on the default workload
+    # HBM traffic and VALU occupancy need hardware counters: taken from the committed rocprofv3 --pmc passes of this
+    # workload (profiles/README.md says which commit), never measured inside this process
+    traffic = valu_busy = prof_src = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp) and E == ENVS_PER_GPU and not args.dense_a:
         try:
-            traffic = json.load(open(tp)).get("mrs_step_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic, valu_busy, prof_src = tj.get("mrs_step_bytes_per_launch"), tj.get("valu_busy"), tj.get("source")
         except Exception:
-            traffic = None
+            pass
     out = {
         "metric": "agent-steps/sec (whole node) at N_AGENTS=64 x4096 envs", "value": value, "unit": "agent-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rollin_steps": args.rollin,
+        "grounded_fraction_after_rollin": grounded, "ms_per_step": elapsed / args.steps * 1e3,
         "host_ms_per_step": host_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "N_AGENTS=64 x %d envs/GPU, ACTION_TYPE=set_target_vel (PID), RETURN_A=True COMM_RANGE=5.0, "
-                               "K_HOPS=3, state_fn=cat(pos,vel), A %s" % (E, "dense fp32" if args.dense_a else "bit-packed"),
+                               "K_HOPS=3, state_fn=cat(pos,vel), A %s%s" % (E, "dense fp32" if args.dense_a else "bit-packed",
+                                                                             ", joint observation all-gathered every step" if world > 1 else ""),
                    "n_agents": N, "n_envs_per_gpu": E, "k_hops": K_HOPS, "comm_range": COMM_RANGE,
-                   "parallelism": "env-sharded x%d, no exchange inside step()" % world if world > 1 else "single GPU"},
+                   "parallelism": "env-sharded x%d, RCCL all-gather of the newest observation slice per step" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_launch": algo_bytes_launch},
+                     "algorithmic_bytes_per_launch": algo_bytes_launch,
+                     "limiter": "VALU issue + phase hand-offs (not HBM, never MFMA): see DESIGN.md section 3", "valu_busy": valu_busy,
+                     "counters_from": prof_src},
     }
-    if gathered is not None:
-        out["with_obs_allgather"] = gathered
+    out.update(extra)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        cb = cpu_baseline()
+        # the literal reference cannot run here (pybullet absent); its Python controller alone
+        # was measured at 305 us per agent-step on one core => an upper bound on what the reference itself could reach
+        cb["reference_python_bracket"] = {"us_per_agent_step_controller_only": 305.0, "agent_steps_per_s_per_core": 1e6 / 305.0,
+                                          "agent_steps_per_s_all_cores": cb["cores"] * 1e6 / 305.0,
+                                          "what": "kind (c) of SURVEY.md 8d: lower bound on the reference's cost (QuadControl Python only, "
+                                                  "no Bullet, no downwash loop); the reference is single-threaded"}
+        out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

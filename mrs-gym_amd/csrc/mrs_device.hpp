@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/mrs_hip.h"
 
@@ -275,12 +276,30 @@ MRS_DEV void rot_small(double s, double c, double d, double &so, double &co)
     so = __builtin_fma(c, d, s) - s * t;
     co = __builtin_fma(-s, d, c) - c * t;
 }
+#ifndef MRS_FAST_RE
+#define MRS_FAST_RE 0
+#endif
 MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re)
 {
     o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
     o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
     o.wx = (float)w[0]; o.wy = (float)w[1]; o.wz = (float)w[2];
     const M3 R = quat_to_matrix_scipy((double)(float)q[0], (double)(float)q[1], (double)(float)q[2], (double)(float)q[3]);
+#if MRS_FAST_RE
+    // Re := R.  from_euler(fl32(as_euler(R))) differs from R by the float32 rounding of the three angles
+    // (<= 2^-24 |angle|, i.e. <= 2e-7 on the matrix elements): the reference's own read-back noise, not signal.
+    // Only the ground-effect switch looks at the angles themselves (Quadcopter.py:80): roll < pi/2 and pitch < pi/2
+    // on the float32 read-backs, restated on the matrix (fl32(roll) < fl32(pi/2) <=> roll < the float32 midpoint
+    // below pi/2 <=> m22 > tan(2.19e-8) m21 or m21 < 0; pitch = asin(-m20) reaches fl32(pi/2) only at gimbal lock).
+    Re = R;
+    o.r00 = (float)R.m00; o.r01 = (float)R.m01; o.r02 = (float)R.m02;
+    o.r10 = (float)R.m10; o.r11 = (float)R.m11; o.r12 = (float)R.m12;
+    o.r20 = (float)R.m20; o.r21 = (float)R.m21; o.r22 = (float)R.m22;
+    const bool roll_ok = (R.m22 > 2.19e-8 * R.m21) || (R.m21 < 0.0);
+    const bool pitch_ok = !((R.m21 * R.m21 + R.m22 * R.m22) < 4.8e-16 && R.m20 < 0.0);
+    o.roll = roll_ok ? 0.f : 2.f; o.pitch = pitch_ok ? 0.f : 2.f; o.yaw = 0.f; // only compared with pi/2 downstream
+    return;
+#endif
     const double h = sqrt64(R.m21 * R.m21 + R.m22 * R.m22);
     const double r = fast_atan2(R.m21, R.m22), pt = fast_atan2(-R.m20, h), y = fast_atan2(R.m10, R.m00);
     o.roll = (float)r; o.pitch = (float)pt; o.yaw = (float)y;
@@ -676,8 +695,11 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
 struct F3 {
     float x, y, z;
 };
-MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, V3 &v, V3 &w)
+// Returns the velocity CHANGES (dv, dw) in float32; the caller adds them to the float64 state (the fused kernel re-reads
+// that from its LDS stash afterwards, so no float64 velocity stays live across the sweeps).
+MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out)
 {
+    dv_out = F3{0.f, 0.f, 0.f}; dw_out = F3{0.f, 0.f, 0.f};
     const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
     const float i0 = (float)K.inv_i0, i1 = (float)K.inv_i1, i2 = (float)K.inv_i2;
     const float im = (float)K.inv_mass;
@@ -692,86 +714,97 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     const double czz = sgn * (hl * R.m22);
     const F3 cx = {(float)(c * R.m00), (float)(c * R.m10), (float)cxz}, cy = {(float)(c * R.m01), (float)(c * R.m11), (float)cyz},
              cz = {(float)(sgn * hl * R.m02), (float)(sgn * hl * R.m12), (float)czz};
-    unsigned active = 0;
+    bool any = false;
     float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
-    // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows
+    // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows.
+    // Branch-free: every lane prepares all four rim points; a point that is not within the contact threshold gets
+    // zero effective masses, which turns its three rows into exact no-ops (impulses stay 0) -- no per-point
+    // exec-mask round trips in the sweeps and nothing to zero-initialise.
     F3 r[4], an[4], ax[4], ay[4];
     const double rdt = K.inv_dt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        ln[k] = lx[k] = ly[k] = Kn[k] = Kx[k] = Ky[k] = rhs[k] = 0.f;
-        r[k] = an[k] = ax[k] = ay[k] = F3{0.f, 0.f, 0.f};
+        ln[k] = lx[k] = ly[k] = 0.f;
         const double rzd = ((k & 1) ? -cxz : cxz) + ((k & 2) ? -cyz : cyz) + czz;
         const double dist = pz + rzd - P.ground_z;
-        if (!(dist <= P.contact_threshold)) continue;
-        active |= 1u << k;
+        const bool act = dist <= P.contact_threshold;
+        any |= act;
         const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
         const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
-        const float rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + cz.z;
+        const float rz = (float)rzd; // lever z rounded once from float64 (as the oracle's gap)
         r[k] = F3{rx, ry, rz};
         // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
         an[k] = F3{Ixx * ry - Ixy * rx, Ixy * ry - Iyy * rx, Ixz * ry - Iyz * rx};
         ax[k] = F3{Ixy * rz - Ixz * ry, Iyy * rz - Iyz * ry, Iyz * rz - Izz * ry};
         ay[k] = F3{-Ixx * rz + Ixz * rx, -Ixy * rz + Iyz * rx, -Ixz * rz + Izz * rx};
-        const float rzs = (float)rzd; // lever z for the effective masses, rounded once from float64 (as the oracle's gap)
-        Kn[k] = __builtin_amdgcn_rcpf(im + (ry * (Ixx * ry - Ixy * rx) - rx * (Ixy * ry - Iyy * rx)));
-        Kx[k] = __builtin_amdgcn_rcpf(im + (rzs * (Iyy * rzs - Iyz * ry) - ry * (Iyz * rzs - Izz * ry)));
-        Ky[k] = __builtin_amdgcn_rcpf(im + (-rzs * (-Ixx * rzs + Ixz * rx) + rx * (-Ixz * rzs + Izz * rx)));
+        // effective masses 1 / (1/m + (r x d) . Iw (r x d))
+        const float kn = __builtin_amdgcn_rcpf(im + (ry * an[k].x - rx * an[k].y));
+        const float kx = __builtin_amdgcn_rcpf(im + (rz * ax[k].y - ry * ax[k].z));
+        const float ky = __builtin_amdgcn_rcpf(im + (rx * ay[k].z - rz * ay[k].x));
+        Kn[k] = act ? kn : 0.f; Kx[k] = act ? kx : 0.f; Ky[k] = act ? ky : 0.f;
         const double vrel0 = v.z + (w.x * (double)ry - w.y * (double)rx);
-        double poserr = 0., velerr = -vrel0;
-        if (dist > 0) velerr -= dist * rdt; else poserr = -dist * P.erp * rdt;
-        rhs[k] = (float)(poserr + velerr);
+        // Bullet-style rhs: open gap -> let the point close it this step; penetration -> erp push-out
+        rhs[k] = (float)(-vrel0 - dist * (dist > 0 ? rdt : P.erp * rdt));
     }
-    if (!active) return;
+    if (!any) return;
     const float v0x = (float)v.x, v0y = (float)v.y, w0x = (float)w.x, w0y = (float)w.y, w0z = (float)w.z;
     const float mu = (float)P.friction;
+    // tangential point velocities of the pre-solve state, per point: the friction rows then need only the CHANGES
+    // dv, dw (3 fused operations per row instead of re-forming v0 + dv, w0 + dw every time)
+    float c0x[4], c0y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c0x[k] = v0x + (w0y * r[k].z - w0z * r[k].y);
+        c0y[k] = v0y + (w0z * r[k].x - w0x * r[k].z);
+    }
     float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;
     // the sweeps gain ~1.5 digits each (measured on the oracle); a lane stops once a whole sweep moved no
     // impulse by more than 1e-7 of the resting impulse m g dt -- float32 cannot resolve less anyway --
-    // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle)
+    // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle).
+    // Convergence is looked at on every second sweep only (the bookkeeping is ~8 % of a sweep).
     const float tol = MRS_CONTACT_TOL * (float)(P.mass * P.gravity * P.dt) + 1e-30f;
-    for (int it = 0; it < P.solver_iters; ++it) {
-        float moved = 0.f;
+    auto sweep = [&](auto track, float &moved) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!(active & (1u << k))) continue;
             const float rx = r[k].x, ry = r[k].y, rz = r[k].z;
             { // normal: u = (ry, -rx, 0)
-                const float dvn = dvz + (dwx * ry - dwy * rx);
-                float nl = ln[k] + Kn[k] * (rhs[k] - dvn);
-                nl = fmaxf(nl, 0.f);                          // v_max_f32 (a compare + select pair otherwise)
+                const float dvn = __builtin_fmaf(-dwy, rx, __builtin_fmaf(dwx, ry, dvz));
+                const float nl = fmaxf(__builtin_fmaf(Kn[k], rhs[k] - dvn, ln[k]), 0.f);
                 const float dl = nl - ln[k];
                 ln[k] = nl;
-                moved = fmaxf(moved, fabsf(dl));
-                dvz += dl * im;
-                dwx += an[k].x * dl; dwy += an[k].y * dl; dwz += an[k].z * dl;
+                if (track) moved = fmaxf(moved, fabsf(dl));
+                dvz = __builtin_fmaf(dl, im, dvz);
+                dwx = __builtin_fmaf(an[k].x, dl, dwx); dwy = __builtin_fmaf(an[k].y, dl, dwy); dwz = __builtin_fmaf(an[k].z, dl, dwz);
             }
             const float lim = mu * ln[k];
             { // friction x: u = (0, rz, -ry)
-                const float vt = (v0x + dvx) + ((w0y + dwy) * rz - (w0z + dwz) * ry);
-                float nl = lx[k] - Kx[k] * vt;
-                nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);  // friction pyramid clamp in one v_med3_f32
+                const float vt = __builtin_fmaf(-dwz, ry, __builtin_fmaf(dwy, rz, c0x[k] + dvx));
+                const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Kx[k], vt, lx[k]), -lim, lim); // friction pyramid: one v_med3_f32
                 const float dl = nl - lx[k];
                 lx[k] = nl;
-                moved = fmaxf(moved, fabsf(dl));
-                dvx += dl * im;
-                dwx += ax[k].x * dl; dwy += ax[k].y * dl; dwz += ax[k].z * dl;
+                if (track) moved = fmaxf(moved, fabsf(dl));
+                dvx = __builtin_fmaf(dl, im, dvx);
+                dwx = __builtin_fmaf(ax[k].x, dl, dwx); dwy = __builtin_fmaf(ax[k].y, dl, dwy); dwz = __builtin_fmaf(ax[k].z, dl, dwz);
             }
             { // friction y: u = (-rz, 0, rx)
-                const float vt = (v0y + dvy) + ((w0z + dwz) * rx - (w0x + dwx) * rz);
-                float nl = ly[k] - Ky[k] * vt;
-                nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);  // friction pyramid clamp in one v_med3_f32
+                const float vt = __builtin_fmaf(-dwx, rz, __builtin_fmaf(dwz, rx, c0y[k] + dvy));
+                const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Ky[k], vt, ly[k]), -lim, lim);
                 const float dl = nl - ly[k];
                 ly[k] = nl;
-                moved = fmaxf(moved, fabsf(dl));
-                dvy += dl * im;
-                dwx += ay[k].x * dl; dwy += ay[k].y * dl; dwz += ay[k].z * dl;
+                if (track) moved = fmaxf(moved, fabsf(dl));
+                dvy = __builtin_fmaf(dl, im, dvy);
+                dwx = __builtin_fmaf(ay[k].x, dl, dwx); dwy = __builtin_fmaf(ay[k].y, dl, dwy); dwz = __builtin_fmaf(ay[k].z, dl, dwz);
             }
         }
+    };
+    for (int it = 0; it < P.solver_iters; it += 2) {
+        float moved = 0.f;
+        sweep(std::false_type{}, moved);
+        if (it + 1 >= P.solver_iters) break;
+        sweep(std::true_type{}, moved);
         if (moved <= tol) break;
     }
-    v.x += (double)dvx; v.y += (double)dvy; v.z += (double)dvz;
-    w.x += (double)dwx; w.y += (double)dwy; w.z += (double)dwz;
+    dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwx, dwy, dwz};
 }
 
 MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
@@ -779,11 +812,22 @@ MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
     V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
 #if MRS_CONTACT_F32
-    contact_solve_f32(P, K, p[2], R, vv, ww);
+    F3 dv, dw;
+    contact_solve_f32(P, K, p[2], R, vv, ww, dv, dw);
+    v[0] += (double)dv.x; v[1] += (double)dv.y; v[2] += (double)dv.z;
+    w[0] += (double)dw.x; w[1] += (double)dw.y; w[2] += (double)dw.z;
 #else
     contact_solve(P, p[2], R, vv, ww);
-#endif
     v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; w[0] = ww.x; w[1] = ww.y; w[2] = ww.z;
+#endif
+}
+
+// The fused kernel's form: only the float32 velocity changes come back (see contact_solve_f32).
+MRS_DEV void contact_stage_delta(const MrsParams &P, const Recips &K, double pz, const double q[4], const double v[3], const double w[3],
+                                 F3 &dv, F3 &dw)
+{
+    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+    contact_solve_f32(P, K, pz, R, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw);
 }
 
 MRS_DEV void integrate_pose(const MrsParams &P, double p[3], double q[4], const double v[3], const double w[3])

@@ -37,19 +37,30 @@ struct StepArgs {
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
 };
 
+// Velocity planes: float64 like Bullet's state, or (MRS_VEL_F32) float32 -- what every consumer of the state reads
+// back anyway (Object.py:78-83); the step still integrates them in float64 registers.
+#ifndef MRS_VEL_F32
+#define MRS_VEL_F32 0
+#endif
+#if MRS_VEL_F32
+typedef float vel_t;
+#else
+typedef double vel_t;
+#endif
+#define VELP(ptr) (reinterpret_cast<vel_t *>(ptr))
 __device__ __forceinline__ void load_state(const MrsBuffers &b, size_t a, size_t T, double p[3], double q[4], double v[3], double w[3])
 {
     p[0] = b.pos[a]; p[1] = b.pos[T + a]; p[2] = b.pos[2 * T + a];
     q[0] = b.quat[a]; q[1] = b.quat[T + a]; q[2] = b.quat[2 * T + a]; q[3] = b.quat[3 * T + a];
-    v[0] = b.vel[a]; v[1] = b.vel[T + a]; v[2] = b.vel[2 * T + a];
-    w[0] = b.angvel[a]; w[1] = b.angvel[T + a]; w[2] = b.angvel[2 * T + a];
+    v[0] = VELP(b.vel)[a]; v[1] = VELP(b.vel)[T + a]; v[2] = VELP(b.vel)[2 * T + a];
+    w[0] = VELP(b.angvel)[a]; w[1] = VELP(b.angvel)[T + a]; w[2] = VELP(b.angvel)[2 * T + a];
 }
 __device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_t T, const double p[3], const double q[4], const double v[3], const double w[3])
 {
     b.pos[a] = p[0]; b.pos[T + a] = p[1]; b.pos[2 * T + a] = p[2];
     b.quat[a] = q[0]; b.quat[T + a] = q[1]; b.quat[2 * T + a] = q[2]; b.quat[3 * T + a] = q[3];
-    b.vel[a] = v[0]; b.vel[T + a] = v[1]; b.vel[2 * T + a] = v[2];
-    b.angvel[a] = w[0]; b.angvel[T + a] = w[1]; b.angvel[2 * T + a] = w[2];
+    VELP(b.vel)[a] = (vel_t)v[0]; VELP(b.vel)[T + a] = (vel_t)v[1]; VELP(b.vel)[2 * T + a] = (vel_t)v[2];
+    VELP(b.angvel)[a] = (vel_t)w[0]; VELP(b.angvel)[T + a] = (vel_t)w[1]; VELP(b.angvel)[2 * T + a] = (vel_t)w[2];
 }
 
 // Workgroup-relative addressing.  Agent a = wg_base + tid for every live lane of k_step / k_observe_adj, so a
@@ -57,14 +68,15 @@ __device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_
 // global_store, with the plane arithmetic on the scalar unit -- instead of one 64-bit VALU add per lane for
 // each of the ~70 plane accesses of a step.
 struct WgBuffers {
-    double *pos, *quat, *vel, *angvel;
+    double *pos, *quat;
+    vel_t *vel, *angvel;
     float *pid, *obs, *rpm;
     uint64_t *adj;
 };
 __device__ __forceinline__ WgBuffers wg_buffers(const StepArgs &A, size_t wg_base)
 {
     WgBuffers w;
-    w.pos = A.b.pos + wg_base; w.quat = A.b.quat + wg_base; w.vel = A.b.vel + wg_base; w.angvel = A.b.angvel + wg_base;
+    w.pos = A.b.pos + wg_base; w.quat = A.b.quat + wg_base; w.vel = VELP(A.b.vel) + wg_base; w.angvel = VELP(A.b.angvel) + wg_base;
     w.pid = A.b.pid ? A.b.pid + wg_base : nullptr;
     w.rpm = A.b.rpm ? A.b.rpm + wg_base : nullptr;
     w.obs = A.b.obs ? A.b.obs + wg_base * (size_t)A.D : nullptr;
@@ -82,8 +94,8 @@ __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size
 {
     b.pos[t] = p[0]; (b.pos + T)[t] = p[1]; (b.pos + 2 * T)[t] = p[2];
     b.quat[t] = q[0]; (b.quat + T)[t] = q[1]; (b.quat + 2 * T)[t] = q[2]; (b.quat + 3 * T)[t] = q[3];
-    b.vel[t] = v[0]; (b.vel + T)[t] = v[1]; (b.vel + 2 * T)[t] = v[2];
-    b.angvel[t] = w[0]; (b.angvel + T)[t] = w[1]; (b.angvel + 2 * T)[t] = w[2];
+    b.vel[t] = (vel_t)v[0]; (b.vel + T)[t] = (vel_t)v[1]; (b.vel + 2 * T)[t] = (vel_t)v[2];
+    b.angvel[t] = (vel_t)w[0]; (b.angvel + T)[t] = (vel_t)w[1]; (b.angvel + 2 * T)[t] = (vel_t)w[2];
 }
 
 // newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
@@ -140,10 +152,10 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
-template <int BLOCK>
+template <int BLOCK, int NFIX = 0>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, uint64_t *row, float4 mine)
 {
-    const bool n64 = (BLOCK == 256) && (A.N == 64);
+    const bool n64 = (BLOCK == 256) && (NFIX == 64 || A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
     else lds_tile[tid] = mine;
     if (n64) wave_lds_sync(); else __syncthreads();
@@ -185,6 +197,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 }
 
 // ------------------------------------------------------------------------------------ step kernel
+#ifndef MRS_DEFER_LOADS
+#define MRS_DEFER_LOADS 0
+#endif
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
 #endif
@@ -194,6 +209,32 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 // between 42k and 79k ticks of a 79k-tick kernel).  Priority falling with progress (pair loop 2, controller 1,
 // pose/outputs 0) keeps them abreast: 34.3 -> 31.8 us per step.  The contact solve, the one serial stretch that
 // three waves of its workgroup wait for, runs at 3.
+// MRS_AB_PRIO: two priority classes of WORKGROUPS (by the workgroup's slot on its CU, HW_ID.tg_id).  All waves of the
+// bench swarm are resident in one round and, at equal priorities, march through load -> forces -> contact -> outputs
+// in lock-step: during the contact hand-off every SIMD is down to its solver waves.  Class A runs ahead of class B,
+// so that A's contact solve overlaps B's forces phase and B's overlaps A's outputs.
+#ifndef MRS_AB_PRIO
+#define MRS_AB_PRIO 0
+#endif
+#ifndef MRS_NFIX64
+#define MRS_NFIX64 0
+#endif
+#ifndef MRS_EARLY_TAIL
+#define MRS_EARLY_TAIL 0
+#endif
+#ifndef MRS_PA_DW
+#define MRS_PA_DW 3
+#define MRS_PA_CTRL 3
+#define MRS_PA_TAIL 2
+#define MRS_PB_DW 1
+#define MRS_PB_CTRL 1
+#define MRS_PB_TAIL 0
+#endif
+#if MRS_AB_PRIO
+#define SETPRIO(both, a, b) do { if (cls_a) __builtin_amdgcn_s_setprio(a); else __builtin_amdgcn_s_setprio(b); } while (0)
+#else
+#define SETPRIO(both, a, b) __builtin_amdgcn_s_setprio(both)
+#endif
 #ifndef MRS_P_DW1
 #define MRS_P_DW1 2
 #define MRS_P_DW2 2
@@ -212,15 +253,17 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 // three-launch form pays it three times (measured: tools/micro/launch_floor.hip).
 // FUSED = false: velocities only; grounded bodies are queued for k_contact, observation/adjacency follow in
 // k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
-template <int ACT, int BLOCK, bool FUSED>
+// NFIX = 64: the instantiation for N_AGENTS = 64 (one env per wave; the generic-N branches fold away), 0: any N.
+template <int ACT, int BLOCK, bool FUSED, int NFIX = 0>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
 {
+    const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / NFIX : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
-    const bool n64 = (BLOCK == 256) && (A.N == 64);
+    const bool n64 = (BLOCK == 256) && (AN == 64);
 
     const int tid = threadIdx.x;
 #ifdef MRS_TIMELINE // diagnostic build (tools/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
@@ -228,22 +271,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const long long t_start = clock64();
     float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
 #define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
+#elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/isa_sections.py)
+#define TL(k) asm volatile("; MRS_MARK " #k)
 #else
 #define TL(k) do { } while (0)
 #endif
-    const int el = tid / A.N;
-    const int i = tid - el * A.N;
-    const int e = blockIdx.x * A.epb + el;
-    const bool live = (el < A.epb) && (e < A.E);
+    const int el = tid / AN;
+    const int i = tid - el * AN;
+    const int e = blockIdx.x * AEPB + el;
+    const bool live = (el < AEPB) && (e < A.E);
     const size_t T = (size_t)A.T;
-    const size_t a = live ? (size_t)e * A.N + i : 0;
+    const size_t a = live ? (size_t)e * AN + i : 0;
     const unsigned la = live ? (unsigned)tid : 0u;                                        // a == wg_base + la
-    const WgBuffers wb = wg_buffers(A, (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N);
+    const WgBuffers wb = wg_buffers(A, (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN);
     constexpr int ADIM = (ACT == MRS_ACT_SET_SPEEDS || ACT == MRS_ACT_SET_CONTROL) ? 4 : 3;
 
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
     float act[4] = {0, 0, 0, 0};
-    if (tid < A.epb) nanflag[tid] = 0;    // N != 64: read after the tile barrier below
+    if (tid < AEPB) nanflag[tid] = 0;    // N != 64: read after the tile barrier below
     if (!FUSED) {                         // LDS slot counter of the three-launch path's compaction
         if (tid == 0) *ncontact = 0;
         if (n64) __syncthreads();         // visible before any wave runs ahead; taken here, before a load is in flight
@@ -253,17 +298,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // action (NaN vote) and the position (LDS tile, pair loop) first, so that the quaternion and the velocities
         // are still in flight while the pair loop runs instead of being waited for up front.
         if (ACT != MRS_ACT_NONE) {
-            const float *ap = A.actions + (size_t)blockIdx.x * (size_t)A.epb * (size_t)A.N * ADIM;
+            const float *ap = A.actions + (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN * ADIM;
 #pragma unroll
             for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
         }
+#if MRS_DEFER_LOADS
+        p[0] = wb.pos[la]; p[1] = (wb.pos + T)[la]; p[2] = (wb.pos + 2 * T)[la];
+#else
         load_state(wb, la, T, p, q, v, w);
+#endif
     }
+#if MRS_DEFER_LOADS
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (n64) {
         lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     } else {
         lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     }
+#if MRS_DEFER_LOADS
+    // The rest of the state is first needed by the controller: issued only now, behind the positions of EVERY wave
+    // (all 4096 waves issue at once; issued up front, these 21 MB would be served before the last wave's position)
+    __builtin_amdgcn_sched_barrier(0);
+    if (live) {
+        q[0] = wb.quat[la]; q[1] = (wb.quat + T)[la]; q[2] = (wb.quat + 2 * T)[la]; q[3] = (wb.quat + 3 * T)[la];
+        v[0] = wb.vel[la]; v[1] = (wb.vel + T)[la]; v[2] = (wb.vel + 2 * T)[la];
+        w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (n64) wave_lds_sync(); else __syncthreads();
     // MRS.py:247-248: any NaN in the env's action aborts that env's step
     bool env_nan = false;
@@ -276,7 +339,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         } else {
             if (live && bad) nanflag[el] = 1;
             __syncthreads();
-            env_nan = (el < A.epb) && nanflag[el];
+            env_nan = (el < AEPB) && nanflag[el];
         }
     }
     TL(0); // loads, tile, NaN vote
@@ -284,7 +347,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool doit = live && !masked && !env_nan;
     if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
-    if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_DW1);
+#if MRS_AB_PRIO
+    bool cls_a = false;
+    if (FUSED) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        cls_a = (MRS_AB_PRIO == 1 ? (hw >> 16) : hw) & 1u; // 1: tg_id[19:16], 2: wave slot id[3:0]
+    }
+#endif
+    if (FUSED) SETPRIO(MRS_P_DW1, MRS_PA_DW, MRS_PB_DW);
     int my_slot = -1;
     bool parked = false;
     double downwash_acc = 0;
@@ -296,13 +367,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // order (deterministic).  Half the transcendental work of the all-pairs loop (N = 256 x 1024 envs: 83.4 -> 77.2 us).
     // Every thread runs the loop: the barriers are workgroup-wide and the trip count depends on N only.
     constexpr int RING_R = 8;
-    const bool ring = FUSED && !n64 && ACT != MRS_ACT_NONE && A.N > 64;
+    const bool ring = FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
     if (ring) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
-        const float4 *tile_env = lds_tile + el * A.N;
+        const float4 *tile_env = lds_tile + el * AN;
         const DownwashConst dc = downwash_const(A.P);
         const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
-        const int half = (A.N - 1) / 2;
+        const int half = (AN - 1) / 2;
         for (int k0 = 1; k0 <= half; k0 += RING_R) {
             float *buf = xb + (((k0 - 1) / RING_R) & 1) * (RING_R * BLOCK);
             float acc32 = 0.f;
@@ -311,13 +382,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 const int k = k0 + r;
                 if (k <= half && doit) {
                     int j = i + k;
-                    j = j >= A.N ? j - A.N : j;
+                    j = j >= AN ? j - AN : j;
                     const float4 pj = tile_env[j];
                     const float dz = pj.z - mz;
                     const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc); // 0 when dz == 0
                     const bool above = dz > 0.f;
                     acc32 += above ? F : 0.f;
-                    buf[r * BLOCK + el * A.N + j] = above ? 0.f : F;
+                    buf[r * BLOCK + el * AN + j] = above ? 0.f : F;
                 }
             }
             __syncthreads();
@@ -326,9 +397,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 if (k0 + r <= half && doit) acc32 += buf[r * BLOCK + tid];
             downwash_acc += (double)acc32;
         }
-        if (!(A.N & 1) && doit) { // antipodal pair: evaluated by both ends, each keeping its own term
-            int j = i + A.N / 2;
-            j = j >= A.N ? j - A.N : j;
+        if (!(AN & 1) && doit) { // antipodal pair: evaluated by both ends, each keeping its own term
+            int j = i + AN / 2;
+            j = j >= AN ? j - AN : j;
             const float4 pj = tile_env[j];
             const float dz = pj.z - mz;
             downwash_acc += (double)(dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f);
@@ -345,11 +416,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // rotation matrices) do not have to survive the 64-iteration loop, which is what keeps the
         // kernel at 4 resident waves per SIMD.
         if (ACT != MRS_ACT_NONE && !ring) {
-            const float4 *tile_env = lds_tile + el * A.N;
+            const float4 *tile_env = lds_tile + el * AN;
             const DownwashConst dc = downwash_const(A.P);
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
 #if !MRS_EXACT_F32
-            if (BLOCK == 256 && A.N == 64) {
+            if (BLOCK == 256 && AN == 64) {
                 // N = 64: the env is exactly this wave.  The pair term depends only on (|dz|, dxy^2) and lands
                 // on the LOWER quadcopter of the pair, so each unordered pair is evaluated once: lane i takes
                 // the pairs (i, i+k), k = 1..31, keeps the term if the other is above, and hands it to lane
@@ -381,7 +452,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #endif
             {
 #pragma unroll 4
-                for (int j = 0; j < A.N; ++j) {
+                for (int j = 0; j < AN; ++j) {
                     const float4 pj = tile_env[j];
 #if MRS_EXACT_F32
                     const float f = downwash_pair(f32sub(pj.x, mx), f32sub(pj.y, my), f32sub(pj.z, mz), dc.pr32, dc.dw1, dc.dw2, dc.dw3);
@@ -393,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
         }
         TL(1); // pair loop
-        if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_CTRL);
+        if (FUSED) SETPRIO(MRS_P_CTRL, MRS_PA_CTRL, MRS_PB_CTRL);
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
             double rpm[4];
@@ -425,9 +496,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            TL(20); // outer loop of the cascade (pos/vel control)
             Observed ob;
             M3 R; // from_euler(float32 euler read-back): only the PID modes use it
             if (NEEDS_PID) observe_ctrl(p, q, v, w, ob, R); else observe<true, true>(p, q, v, w, ob);
+            TL(21); // read-back + rotation matrices
             if (NEEDS_PID) {
                 float *g = wb.pid + la;
                 s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
@@ -511,6 +584,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
             fb.z += downwash_acc;
         }
+        TL(22); // rotor forces, ground effect, drag
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
         TL(3); // forces + velocity integration
         if (FUSED) {
@@ -553,13 +627,27 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         int n = 0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) { n += wcnt[k]; wend[k] = n; }
+#if MRS_EARLY_TAIL
+        // A wave without a share of the solve would only wait at the barrier below: it finishes its free-flying lanes
+        // now (pose, state store, observation slice) and leaves their post-step position in the stash for the
+        // adjacency phase; only its grounded lanes are left for after the solve.
+        const bool early = n > 0 && (tid & ~63) >= n; // wave-uniform, recomputed after the solve (nothing kept live)
+        if (early) {
+            if (doit && !parked) {
+                integrate_pose(A.P, p, q, v, w);
+                store_state(wb, la, T, p, q, v, w);
+                if (A.b.obs && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+                sp[tid] = p[0]; sp[BLOCK + tid] = p[1]; sp[2 * BLOCK + tid] = p[2];
+            }
+        }
+#endif
         if (n > 0) { // uniform over the workgroup
             // The solving wave is the workgroup's critical path (three waves wait for it at the barrier below) but
             // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
             // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
             // priority lets it issue whenever it is ready.
             __builtin_amdgcn_s_setprio(3);
-            for (int sl = tid; sl < n; sl += BLOCK) {
+            if (const int sl = tid; sl < n) { // n <= BLOCK: every lane lists at most itself
                 int seg = 0;
 #pragma unroll
                 for (int k = 0; k + 1 < NW; ++k) seg += (sl >= wend[k]);
@@ -567,6 +655,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #pragma unroll
                 for (int k = 0; k + 1 < NW; ++k) start = (seg == k + 1) ? wend[k] : start;
                 const int b = clist[seg * 64 + (sl - start)];
+#if MRS_CONTACT_F32
+                F3 dv, dw;
+                {
+                    const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
+                    const double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
+                    const double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
+                    contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw);
+                }
+                // the float64 velocities are read again from the stash: nothing float64 is live across the sweeps
+                sp[7 * BLOCK + b] += (double)dv.x; sp[8 * BLOCK + b] += (double)dv.y; sp[9 * BLOCK + b] += (double)dv.z;
+                sp[10 * BLOCK + b] += (double)dw.x; sp[11 * BLOCK + b] += (double)dw.y; sp[12 * BLOCK + b] += (double)dw.z;
+#else
                 const double pp[3] = {0., 0., sp[2 * BLOCK + b]};
                 const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
                 double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
@@ -574,17 +674,27 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 contact_stage(A.P, A.rc, pp, qq, vv, ww);
                 sp[7 * BLOCK + b] = vv[0]; sp[8 * BLOCK + b] = vv[1]; sp[9 * BLOCK + b] = vv[2];
                 sp[10 * BLOCK + b] = ww[0]; sp[11 * BLOCK + b] = ww[1]; sp[12 * BLOCK + b] = ww[2];
+#endif
             }
-            __builtin_amdgcn_s_setprio(0);
+            SETPRIO(0, MRS_PA_TAIL, MRS_PB_TAIL);
             TL(5); // own share of the contact solve
             __syncthreads();
         }
         TL(6); // barrier 2
-        __builtin_amdgcn_s_setprio(MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
+        SETPRIO(MRS_P_TAIL, MRS_PA_TAIL, MRS_PB_TAIL); // last phase, lowest priority: see MRS_P_* above
         p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
         q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
         v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
         w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
+#if MRS_EARLY_TAIL
+        const bool todo = doit && !((n > 0 && (tid & ~63) >= n) && !parked);
+        if (todo) {
+            integrate_pose(A.P, p, q, v, w);
+            store_state(wb, la, T, p, q, v, w);
+        }
+        TL(7); // pose + store
+        if (A.b.obs && live && A.n_obs > 0 && (todo || !doit)) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+#else
         if (doit) {
             integrate_pose(A.P, p, q, v, w);
             store_state(wb, la, T, p, q, v, w);
@@ -592,8 +702,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         TL(7); // pose + store
         if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+#endif
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
-        if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        if (A.do_adj) adjacency_phase<BLOCK, NFIX>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)AW, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
         TL(8); // observation + adjacency
         return;
     }
@@ -709,11 +820,11 @@ __global__ void k_set_state(const SetArgs S)
     const size_t T = S.T;
     if (S.mask && !S.mask[a / S.N]) return;
     if (S.pos) for (int k = 0; k < 3; ++k) S.b.pos[k * T + a] = (double)S.pos[a * 3 + k];
-    if (S.vel) for (int k = 0; k < 3; ++k) S.b.vel[k * T + a] = (double)S.vel[a * 3 + k];
-    if (S.angvel) for (int k = 0; k < 3; ++k) S.b.angvel[k * T + a] = (double)S.angvel[a * 3 + k];
+    if (S.vel) for (int k = 0; k < 3; ++k) VELP(S.b.vel)[k * T + a] = (vel_t)S.vel[a * 3 + k];
+    if (S.angvel) for (int k = 0; k < 3; ++k) VELP(S.b.angvel)[k * T + a] = (vel_t)S.angvel[a * 3 + k];
     if (S.pos64) for (int k = 0; k < 3; ++k) S.b.pos[k * T + a] = S.pos64[a * 3 + k];
-    if (S.vel64) for (int k = 0; k < 3; ++k) S.b.vel[k * T + a] = S.vel64[a * 3 + k];
-    if (S.angvel64) for (int k = 0; k < 3; ++k) S.b.angvel[k * T + a] = S.angvel64[a * 3 + k];
+    if (S.vel64) for (int k = 0; k < 3; ++k) VELP(S.b.vel)[k * T + a] = (vel_t)S.vel64[a * 3 + k];
+    if (S.angvel64) for (int k = 0; k < 3; ++k) VELP(S.b.angvel)[k * T + a] = (vel_t)S.angvel64[a * 3 + k];
     if (S.quat64) for (int k = 0; k < 4; ++k) S.b.quat[k * T + a] = S.quat64[a * 4 + k];
     if (S.ori) {
         double q[4];
@@ -856,7 +967,7 @@ __global__ void k_spawn(const SpawnArgs S)
         double q[4];
         euler_to_quat((double)eul[0], (double)eul[1], (double)eul[2], q);
         for (int k = 0; k < 4; ++k) S.b.quat[k * T + a] = q[k];
-        for (int k = 0; k < 3; ++k) { S.b.vel[k * T + a] = 0.0; S.b.angvel[k * T + a] = 0.0; }
+        for (int k = 0; k < 3; ++k) { VELP(S.b.vel)[k * T + a] = 0; VELP(S.b.angvel)[k * T + a] = 0; }
     }
 }
 
@@ -1115,6 +1226,10 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
     const int grid = (h->E + h->epb - 1) / h->epb;
     const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
     // fused: + compacted lane list + 13 float64 state planes + per-wave counts (36 888 B; 4 workgroups per CU fit the 160 KB LDS)
+#if MRS_NFIX64
+    if (fused && h->N == 64) hipLaunchKernelGGL((k_step<ACT, 256, true, 64>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
+    else
+#endif
     if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
     else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, A);

@@ -425,7 +425,7 @@ def test_data_generation_loop_like_the_reference_example():
 def test_bench_contract_single_and_two_ranks():
     """bench.py end to end at a small size: one JSON line with the contract's keys for N=1, and the N>1 launch the
     driver uses (torch.distributed.run, one rank per process) rehearsed with two gloo ranks sharing this one GPU:
-    weak scaling, per-step joint-observation all-gather reported beside `value`."""
+    weak scaling, `value` with the per-step joint-observation all-gather, the exchange-free rate beside it."""
     import json
     import subprocess
     import sys
@@ -441,6 +441,7 @@ def test_bench_contract_single_and_two_ranks():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["unit"] == "agent-steps/s"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["config"]["workload"]
+    assert d["rollin_steps"] == 700 and d["dense_a"]["value"] > 0 and d["dense_a"]["ms_per_step"] > 0
     env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
@@ -450,4 +451,7 @@ def test_bench_contract_single_and_two_ranks():
     assert len(lines) == 1                                       # rank 0 only
     d2 = json.loads(lines[0])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0
-    assert d2["with_obs_allgather"]["value"] > 0 and d2["with_obs_allgather"]["bytes_sent_per_rank_per_step"] == 64 * 64 * 6 * 4
+    # N > 1: `value` includes the per-step joint-observation all-gather (BASELINE config 5); the exchange-free rate is beside it
+    assert "all-gather" in d2["config"]["parallelism"]
+    assert d2["no_exchange"]["value"] > 0 and d2["obs_allgather"]["bytes_sent_per_rank_per_step"] == 64 * 64 * 6 * 4
+    assert d2["obs_allgather"]["xgmi_floor_ms"] > 0
