@@ -164,6 +164,27 @@ int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_inde
  * adjacency it is handed (it substitutes ones - eye, Reynolds.py:83), so none is taken here. */
 int mrs_reynolds(MrsHandle *h, const float *x_prev, int D, float *actions, void *stream);
 
+/* ---- geometry sensors: Object.py:100-174 against the analytic scene of env_generator('simple')
+ * (ground box of plane.urdf:24 + one collision cylinder per quadcopter, cf2x.urdf:34).  Replaces p.rayTestBatch,
+ * p.getClosestPoints, p.getContactPoints, p.getOverlappingObjects.  Not part of mrs_step: call when a callback asks. */
+
+/* Object.raycast (Object.py:150-174), for EVERY quadcopter of every env at once: each casts the same n_rays rays.
+ * offset, directions: (n_rays,3) float32 device arrays (directions are scaled by `range` as :151 does, on a copy);
+ * body != 0: both are body-frame vectors (:158-160).  Outputs, row-major device arrays:
+ *   hit_obj   (E,N,R) int32  -1 = miss, 0..N-1 = quadcopter of the same env, N = ground   ("object", :164)
+ *   pos_world (E,N,R,3)      hit position minus the rotated offset                         ("pos world", :165)
+ *   pos_body  (E,N,R,3)      R^T pos_world - R^T pos                                       ("pos", :166)
+ *   dist      (E,N,R)        |pos_body|                                                    ("dist", :171); misses are zeros */
+int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offset, const float *directions, int n_rays, int body,
+                float range, int32_t *hit_obj, float *pos_world, float *pos_body, float *dist, void *stream);
+
+/* Object.get_dist (Object.py:119-133) for every ordered pair: dist (E,N,N+1) float32, column j < N = quadcopter j of
+ * the same env (0 on the diagonal, 0 when the hulls overlap), column N = the ground (signed: negative when sunk in);
+ * +inf where the bodies are further apart than max_dist (the reference returns an empty result there, :121-122).
+ * p_self / p_other (optional, (E,N,N+1,3) float32): "closest pos self" / "closest pos other" in world coordinates.
+ * collision() (:136-137), get_contact_points (:100-116) and get_closest_objects (:140-147) are thresholds on this. */
+int mrs_proximity(MrsHandle *h, const MrsBuffers *b, double max_dist, float *dist, float *p_self, float *p_other, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1412,3 +1412,6 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn launch");
 }
+
+// ---------------------------------------------------------------------------------------------------- sensors
+#include "mrs_sensors.hpp"

@@ -1,0 +1,361 @@
+// mrs_sensors.hpp -- the reference's geometry sensors (mrsgym/Object.py:100-174), batched over every quadcopter of
+// every env, against the analytic scene of env_generator('simple') (EnvCreator.py:7-13): the ground box of
+// plane.urdf:24 (30 x 30 x 1 m at the origin, top face z = ground_z) and one collision cylinder per quadcopter
+// (cf2x.urdf:34, axis = body z).  Included at the end of mrs_kernels.hip (same translation unit: MrsHandle, fail()).
+//
+// Not on the step() hot path: float64 geometry, one lane per ray / per pair, the env's cylinders staged in LDS.
+// Parity with pybullet's rayTestBatch / getClosestPoints is unpinned (pybullet absent); the checker is
+// oracle/mrs_sensors.c, itself certified by brute force (tests/test_oracle_sensors.py).
+#pragma once
+
+namespace mrs_sense {
+
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 mk(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return D3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+constexpr double kGroundHalfXY = 15.0, kGroundThick = 1.0; // plane.urdf:24
+
+// centre and unit axis (third column of Bullet's matrix of the state quaternion) of every cylinder of the env -> LDS
+__device__ __forceinline__ void stage_cylinders(const MrsBuffers &b, size_t T, size_t a0, int N, double *lc)
+{
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const size_t a = a0 + j;
+        const double qx = b.quat[a], qy = b.quat[T + a], qz = b.quat[2 * T + a], qw = b.quat[3 * T + a];
+        const double s = 2.0 / (qx * qx + qy * qy + qz * qz + qw * qw);
+        double ax = (qx * qz + qw * qy) * s, ay = (qy * qz - qw * qx) * s, az = 1.0 - (qx * qx + qy * qy) * s;
+        const double n = 1.0 / sqrt(ax * ax + ay * ay + az * az);
+        lc[6 * j] = b.pos[a]; lc[6 * j + 1] = b.pos[T + a]; lc[6 * j + 2] = b.pos[2 * T + a];
+        lc[6 * j + 3] = ax * n; lc[6 * j + 4] = ay * n; lc[6 * j + 5] = az * n;
+    }
+}
+
+// segment o + t d, t in [0,1], against the capped cylinder (centre c, unit axis a); entering parameter or -1.
+// A segment that starts inside reports nothing (Bullet's convex cast from inside a convex shape).
+__device__ __forceinline__ double ray_cylinder(D3 o, D3 d, D3 c, D3 a, double rc, double hl)
+{
+    const D3 oc = o - c;
+    const double oz = dot(oc, a), dz = dot(d, a);
+    const D3 orad = oc - oz * a, drad = d - dz * a;
+    const double cc = dot(orad, orad) - rc * rc;
+    if (cc <= 0 && fabs(oz) <= hl) return -1.0;
+    double best = -1.0;
+    const double aa = dot(drad, drad);
+    if (aa > 0) {
+        const double bb = dot(orad, drad), disc = bb * bb - aa * cc;
+        if (disc >= 0) {
+            const double t = (-bb - sqrt(disc)) / aa;
+            if (t >= 0 && t <= 1 && fabs(oz + t * dz) <= hl) best = t;
+        }
+    }
+    if (dz != 0) {
+        const double t = ((dz > 0 ? -hl : hl) - oz) / dz;
+        if (t >= 0 && t <= 1) {
+            const D3 r = orad + t * drad;
+            if (dot(r, r) <= rc * rc && (best < 0 || t < best)) best = t;
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ double ray_box(D3 o, D3 d, D3 lo, D3 hi)
+{
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) inside &= (oo[k] >= l[k] && oo[k] <= h[k]);
+    if (inside) return -1.0;
+    double t0 = 0, t1 = 1;
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (dd[k] == 0) {
+            miss |= (oo[k] < l[k] || oo[k] > h[k]);
+        } else {
+            double x = (l[k] - oo[k]) / dd[k], y = (h[k] - oo[k]) / dd[k];
+            if (x > y) { const double s = x; x = y; y = s; }
+            t0 = fmax(t0, x); t1 = fmin(t1, y);
+        }
+    }
+    return (miss || t0 > t1) ? -1.0 : t0;
+}
+
+struct RayArgs {
+    MrsBuffers b;
+    const float *offset, *dirs; // [R][3]
+    int32_t *hit;               // (E,N,R): -1 none, 0..N-1 quadcopter, N ground
+    float *pos_world, *pos_body, *dist;
+    int E, N, R, body;
+    float range;
+    double rc, hl, ground_z;
+    size_t T;
+};
+
+// Object.raycast (Object.py:150-174): one workgroup per env, lanes stride over (agent, ray)
+__global__ __launch_bounds__(256) void k_raycast(const RayArgs S)
+{
+    extern __shared__ double lc[]; // [N][6] centre, axis
+    const int e = blockIdx.x;
+    const size_t a0 = (size_t)e * S.N, T = S.T;
+    stage_cylinders(S.b, T, a0, S.N, lc);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S.N * S.R; idx += blockDim.x) {
+        const int i = idx / S.R, r = idx - i * S.R;
+        const size_t a = a0 + i;
+        // what get_ori(mat=True) / get_pos() hand to raycast (Object.py:86-97): float32 of the float32-truncated state
+        const double pd[3] = {S.b.pos[a], S.b.pos[T + a], S.b.pos[2 * T + a]};
+        const double qd[4] = {S.b.quat[a], S.b.quat[T + a], S.b.quat[2 * T + a], S.b.quat[3 * T + a]};
+        const double zero[3] = {0, 0, 0};
+        mrs::Observed ob;
+        mrs::observe<false, true>(pd, qd, zero, zero, ob);
+        const float Rm[9] = {ob.r00, ob.r01, ob.r02, ob.r10, ob.r11, ob.r12, ob.r20, ob.r21, ob.r22};
+        const float opos[3] = {ob.px, ob.py, ob.pz};
+        // :151 directions *= RANGE, :159-163 rotate (body=True), start = offset + pos, end = directions + start: float32
+        float dl[3], of[3], dw[3], ofw[3], st[3], en[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dl[k] = mrs::f32mul(S.dirs[3 * r + k], S.range); of[k] = S.offset[3 * r + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (S.body) {
+                ofw[k] = mrs::f32add(mrs::f32add(mrs::f32mul(Rm[3 * k], of[0]), mrs::f32mul(Rm[3 * k + 1], of[1])), mrs::f32mul(Rm[3 * k + 2], of[2]));
+                dw[k] = mrs::f32add(mrs::f32add(mrs::f32mul(Rm[3 * k], dl[0]), mrs::f32mul(Rm[3 * k + 1], dl[1])), mrs::f32mul(Rm[3 * k + 2], dl[2]));
+            } else { ofw[k] = of[k]; dw[k] = dl[k]; }
+            st[k] = mrs::f32add(ofw[k], opos[k]);
+            en[k] = mrs::f32add(dw[k], st[k]);
+        }
+        const D3 o = mk(st[0], st[1], st[2]), d = mk((double)en[0] - st[0], (double)en[1] - st[1], (double)en[2] - st[2]);
+        double best = ray_box(o, d, mk(-kGroundHalfXY, -kGroundHalfXY, S.ground_z - kGroundThick), mk(kGroundHalfXY, kGroundHalfXY, S.ground_z));
+        int obj = best >= 0 ? S.N : -1;
+        for (int j = 0; j < S.N; ++j) {
+            const double t = ray_cylinder(o, d, mk(lc[6 * j], lc[6 * j + 1], lc[6 * j + 2]), mk(lc[6 * j + 3], lc[6 * j + 4], lc[6 * j + 5]), S.rc, S.hl);
+            if (t >= 0 && (best < 0 || t < best)) { best = t; obj = j; }
+        }
+        const size_t o3 = ((size_t)a * S.R + r) * 3, o1 = (size_t)a * S.R + r;
+        S.hit[o1] = obj;
+        float pw[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+        if (obj >= 0) {
+            const double hit[3] = {o.x + best * d.x, o.y + best * d.y, o.z + best * d.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pw[k] = mrs::f32sub((float)hit[k], ofw[k]); // :166 "pos world" = hit - rotated offset
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {                                           // :167 pos = R^T pos_world - R^T pos
+                const float x = mrs::f32add(mrs::f32add(mrs::f32mul(Rm[k], pw[0]), mrs::f32mul(Rm[3 + k], pw[1])), mrs::f32mul(Rm[6 + k], pw[2]));
+                const float y = mrs::f32add(mrs::f32add(mrs::f32mul(Rm[k], opos[0]), mrs::f32mul(Rm[3 + k], opos[1])), mrs::f32mul(Rm[6 + k], opos[2]));
+                pb[k] = mrs::f32sub(x, y);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { S.pos_world[o3 + k] = pw[k]; S.pos_body[o3 + k] = pb[k]; }
+        S.dist[o1] = sqrtf(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]); // :171 (zeros on a miss, :168-170)
+    }
+}
+
+// ---- closest points of two convex cylinders: GJK with Ericson's closest-point-on-simplex cases (same algorithm as
+// the oracle's gjk_cyl_cyl; the simplex lives in registers / scratch, this is not a hot kernel)
+struct Cyl {
+    D3 c, a;
+};
+__device__ __forceinline__ D3 cyl_support(const Cyl &s, D3 d, double rc, double hl)
+{
+    const double da = dot(d, s.a);
+    const D3 rad = d - da * s.a;
+    const double n = sqrt(dot(rad, rad));
+    D3 r = s.c + (da >= 0 ? hl : -hl) * s.a;
+    if (n > 1e-300) r = r + (rc / n) * rad;
+    return r;
+}
+struct Simplex {
+    D3 w[4], a[4], b[4];
+    double l[4];
+    int n;
+};
+__device__ inline void sx_keep(Simplex &s, int i0, int i1, int i2, int n, double l0, double l1, double l2)
+{
+    const int idx[3] = {i0, i1, i2};
+    const double l[3] = {l0, l1, l2};
+    const Simplex t = s;
+    for (int k = 0; k < n; ++k) { s.w[k] = t.w[idx[k]]; s.a[k] = t.a[idx[k]]; s.b[k] = t.b[idx[k]]; s.l[k] = l[k]; }
+    s.n = n;
+}
+__device__ inline void sx_segment(Simplex &s)
+{
+    const D3 A = s.w[0], ab = s.w[1] - A;
+    const double t = -dot(A, ab), dn = dot(ab, ab);
+    if (t <= 0 || dn <= 0) { s.n = 1; s.l[0] = 1; return; }
+    if (t >= dn) { sx_keep(s, 1, 0, 0, 1, 1, 0, 0); return; }
+    s.l[1] = t / dn; s.l[0] = 1 - s.l[1];
+}
+__device__ inline void sx_triangle(Simplex &s)
+{
+    const D3 a = s.w[0], b = s.w[1], c = s.w[2], ab = b - a, ac = c - a, ap = -1.0 * a;
+    const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { sx_keep(s, 0, 0, 0, 1, 1, 0, 0); return; }
+    const D3 bp = -1.0 * b;
+    const double d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { sx_keep(s, 1, 0, 0, 1, 1, 0, 0); return; }
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); sx_keep(s, 0, 1, 0, 2, 1 - v, v, 0); return; }
+    const D3 cp = -1.0 * c;
+    const double d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { sx_keep(s, 2, 0, 0, 1, 1, 0, 0); return; }
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); sx_keep(s, 0, 2, 0, 2, 1 - w, w, 0); return; }
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); sx_keep(s, 1, 2, 0, 2, 1 - w, w, 0); return; }
+    const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+    s.l[0] = 1 - v - w; s.l[1] = v; s.l[2] = w;
+}
+__device__ inline D3 sx_point(const Simplex &s)
+{
+    D3 p = mk(0, 0, 0);
+    for (int k = 0; k < s.n; ++k) p = p + s.l[k] * s.w[k];
+    return p;
+}
+__device__ inline bool sx_tetra(Simplex &s)
+{
+    const int F[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
+    const int O[4] = {3, 1, 2, 0};
+    Simplex best = s;
+    double bd = -1;
+    bool outside_any = false;
+    for (int f = 0; f < 4; ++f) {
+        const D3 a = s.w[F[f][0]], b = s.w[F[f][1]], c = s.w[F[f][2]], d = s.w[O[f]];
+        const D3 n = cross(b - a, c - a);
+        const double so = dot(-1.0 * a, n), sd = dot(d - a, n);
+        if (so * sd < 0 || sd == 0) {
+            outside_any = true;
+            Simplex t = s;
+            sx_keep(t, F[f][0], F[f][1], F[f][2], 3, 0, 0, 0);
+            sx_triangle(t);
+            const D3 q = sx_point(t);
+            const double dd = dot(q, q);
+            if (bd < 0 || dd < bd) { bd = dd; best = t; }
+        }
+    }
+    if (!outside_any) return true;
+    s = best;
+    return false;
+}
+__device__ inline double gjk_cyl_cyl(const Cyl &A, const Cyl &B, double rc, double hl, D3 &pa, D3 &pb)
+{
+    Simplex s;
+    s.n = 0;
+    D3 v = A.c - B.c;
+    if (dot(v, v) < 1e-24) v = mk(1, 0, 0);
+    for (int it = 0; it < 64; ++it) {
+        const D3 sa = cyl_support(A, -1.0 * v, rc, hl), sb = cyl_support(B, v, rc, hl), w = sa - sb;
+        const double vv = dot(v, v);
+        if (s.n > 0 && vv - dot(v, w) <= 1e-14 * vv + 1e-30) break;
+        bool dup = false;
+        for (int k = 0; k < s.n; ++k) dup |= (s.w[k].x == w.x && s.w[k].y == w.y && s.w[k].z == w.z);
+        if (dup) break;
+        const Simplex prev = s;
+        s.w[s.n] = w; s.a[s.n] = sa; s.b[s.n] = sb; s.n++;
+        bool inside = false;
+        if (s.n == 1) s.l[0] = 1;
+        else if (s.n == 2) sx_segment(s);
+        else if (s.n == 3) sx_triangle(s);
+        else inside = sx_tetra(s);
+        if (inside) {
+            const D3 e1 = s.w[1] - s.w[0], e2 = s.w[2] - s.w[0], e3 = s.w[3] - s.w[0], o = -1.0 * s.w[0];
+            const double vol = dot(e1, cross(e2, e3));
+            double l1 = dot(o, cross(e2, e3)) / vol, l2 = dot(e1, cross(o, e3)) / vol, l3 = dot(e1, cross(e2, o)) / vol;
+            if (!(fabs(vol) > 0)) { l1 = l2 = l3 = 0.25; }
+            pa = pb = (1 - l1 - l2 - l3) * s.a[0] + l1 * s.a[1] + l2 * s.a[2] + l3 * s.a[3];
+            return 0.0;
+        }
+        const D3 vn = sx_point(s);
+        if (prev.n > 0 && dot(vn, vn) >= vv) { s = prev; break; }
+        v = vn;
+        if (dot(v, v) < 1e-24) break;
+    }
+    D3 a = mk(0, 0, 0), b = mk(0, 0, 0);
+    for (int k = 0; k < s.n; ++k) { a = a + s.l[k] * s.a[k]; b = b + s.l[k] * s.b[k]; }
+    pa = a; pb = b;
+    const D3 ab = a - b;
+    const double d = sqrt(dot(ab, ab));
+    return d < 1e-12 ? 0.0 : d;
+}
+
+struct ProxArgs {
+    MrsBuffers b;
+    float *dist, *p_self, *p_other; // (E,N,N+1), (E,N,N+1,3) x2 (optional)
+    int E, N;
+    double rc, hl, ground_z, max_dist;
+    size_t T;
+};
+
+// Object.get_dist (Object.py:119-133) for every ordered pair of an env + every quadcopter against the ground:
+// one workgroup per env, lanes stride over (i, j), j = N being the ground.  Pairs whose bounding spheres are already
+// further apart than max_dist are reported as +inf without running GJK (the reference's MAX_DIST returns nothing there).
+__global__ __launch_bounds__(256) void k_proximity(const ProxArgs S)
+{
+    extern __shared__ double lc[];
+    const int e = blockIdx.x, N = S.N;
+    const size_t a0 = (size_t)e * N;
+    stage_cylinders(S.b, S.T, a0, N, lc);
+    __syncthreads();
+    const double bound = sqrt(S.rc * S.rc + S.hl * S.hl);
+    for (int idx = threadIdx.x; idx < N * (N + 1); idx += blockDim.x) {
+        const int i = idx / (N + 1), j = idx - i * (N + 1);
+        const Cyl me = {mk(lc[6 * i], lc[6 * i + 1], lc[6 * i + 2]), mk(lc[6 * i + 3], lc[6 * i + 4], lc[6 * i + 5])};
+        D3 pa = me.c, pb = me.c;
+        double d = 0;
+        if (j == N) {
+            // lowest point of the cylinder = support point along -z (the middle of the lowest line / cap when degenerate)
+            const double az = me.a.z;
+            D3 low = me.c + (az > 1e-12 ? -S.hl : (az < -1e-12 ? S.hl : 0.0)) * me.a;
+            const D3 rad = mk(0, 0, -1) - (-az) * me.a;
+            const double n = sqrt(dot(rad, rad));
+            if (n > 1e-9) low = low + (S.rc / n) * rad;
+            pa = low; pb = mk(low.x, low.y, S.ground_z);
+            d = low.z - S.ground_z; // signed: < 0 = sunk into the ground
+        } else if (j != i) {
+            const Cyl o = {mk(lc[6 * j], lc[6 * j + 1], lc[6 * j + 2]), mk(lc[6 * j + 3], lc[6 * j + 4], lc[6 * j + 5])};
+            const D3 cc = me.c - o.c;
+            if (sqrt(dot(cc, cc)) - 2 * bound > S.max_dist) d = INFINITY;
+            else d = gjk_cyl_cyl(me, o, S.rc, S.hl, pa, pb);
+        }
+        const size_t o1 = (a0 + i) * (size_t)(N + 1) + j;
+        S.dist[o1] = (float)d;
+        if (S.p_self) { S.p_self[3 * o1] = (float)pa.x; S.p_self[3 * o1 + 1] = (float)pa.y; S.p_self[3 * o1 + 2] = (float)pa.z; }
+        if (S.p_other) { S.p_other[3 * o1] = (float)pb.x; S.p_other[3 * o1 + 1] = (float)pb.y; S.p_other[3 * o1 + 2] = (float)pb.z; }
+    }
+}
+
+} // namespace mrs_sense
+
+extern "C" int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offset, const float *directions, int n_rays, int body,
+                           float range, int32_t *hit_obj, float *pos_world, float *pos_body, float *dist, void *stream)
+{
+    if (!h || !b || !offset || !directions || !hit_obj || !pos_world || !pos_body || !dist) return fail(MRS_E_ARG, "mrs_raycast: NULL argument");
+    if (n_rays < 1) return fail(MRS_E_ARG, "mrs_raycast: n_rays must be >= 1");
+    DeviceGuard dg(h->device);
+    mrs_sense::RayArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.offset = offset; S.dirs = directions; S.hit = hit_obj; S.pos_world = pos_world; S.pos_body = pos_body; S.dist = dist;
+    S.E = h->E; S.N = h->N; S.R = n_rays; S.body = body; S.range = range;
+    S.rc = h->P.coll_radius; S.hl = h->P.coll_half_len; S.ground_z = h->P.ground_z; S.T = (size_t)h->E * h->N;
+    hipLaunchKernelGGL(mrs_sense::k_raycast, dim3(h->E), dim3(256), (size_t)h->N * 6 * sizeof(double), (hipStream_t)stream, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_raycast launch");
+}
+
+extern "C" int mrs_proximity(MrsHandle *h, const MrsBuffers *b, double max_dist, float *dist, float *p_self, float *p_other, void *stream)
+{
+    if (!h || !b || !dist) return fail(MRS_E_ARG, "mrs_proximity: NULL argument");
+    DeviceGuard dg(h->device);
+    mrs_sense::ProxArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.dist = dist; S.p_self = p_self; S.p_other = p_other; S.E = h->E; S.N = h->N;
+    S.rc = h->P.coll_radius; S.hl = h->P.coll_half_len; S.ground_z = h->P.ground_z; S.max_dist = max_dist; S.T = (size_t)h->E * h->N;
+    hipLaunchKernelGGL(mrs_sense::k_proximity, dim3(h->E), dim3(256), (size_t)h->N * 6 * sizeof(double), (hipStream_t)stream, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_proximity launch");
+}

@@ -4,8 +4,9 @@ Environment  <- mrsgym/Environment.py:84-124 (the per-agent loops become tensor 
 QuadView     <- mrsgym/Object.py:78-97 + mrsgym/Quadcopter.py:21-22 (what a state_fn may call)
 StateFnCompiler turns a user state_fn(quad) into either a fused observation spec (written by the
 step kernel itself) or a vmapped tensor program -- never a Python loop over E*N agents.
-GUI / debug / sensor entry points (Environment.py:127-306, Object.py:100-195) are accepted and
-ignored: there is no GUI on a headless GPU env.
+GUI / debug entry points (Environment.py:127-306) are accepted and ignored: there is no GUI on a headless GPU
+env.  The geometry sensors of Object.py:100-174 (raycast, get_dist,
+get_contact_points, collision, get_closest_objects) are batched kernels against the analytic scene (mrs_sensors.hpp).
 """
 import warnings
 
@@ -78,11 +79,114 @@ class QuadView:
                      vel=widen(vel, sh.view(sh.vel).to(torch.float32)),
                      angvel=widen(angvel, sh.view(sh.angvel).to(torch.float32)))
 
-    # sensors: out of scope on the accelerated path
-    def collision(self):
-        raise NotImplementedError("contact/raycast/camera sensors are not on the accelerated path")
+    # ------------------------------------------------------------------ sensors (Object.py:100-174)
+    # One batched kernel answers the query for EVERY quadcopter of every env (Environment.raycast / proximity, cached
+    # until the state changes); a QuadView picks its own row, so a per-agent callback loop costs one launch, not N.
+    def raycast(self, offset=None, directions=None, body=True, RANGE=100.0):  # Object.py:150-174
+        """dict: "object" (list of QuadView / GroundView / None for one env, else (E,R) int tensor: -1 miss, N ground),
+        "pos world", "pos" (R,3), "dist" (R,).  The reference scales `directions` by RANGE IN PLACE (:151), which also
+        corrupts its own default argument from the second call on; the caller's tensor is left alone here."""
+        offset = torch.zeros(3) if offset is None else offset
+        directions = torch.tensor([1., 0., 0.]) if directions is None else directions
+        out = self.env.raycast(offset, directions, body=body, RANGE=RANGE)
+        one = self.env._mrs.shard.E == 1
+        pick = (lambda t: t[self._i]) if one else (lambda t: t[:, self._i])
+        res = {k: pick(v) for k, v in out.items()}
+        if one:
+            res["object"] = [self.env.object_by_index(int(j)) for j in res["object"].tolist()]
+        return res
 
-    get_contact_points = get_dist = get_closest_objects = raycast = get_image = lambda self, *a, **k: QuadView.collision(self)
+    def get_dist(self, other, MAX_DIST=float('inf'), body=False):  # Object.py:119-133
+        """One env: the reference's dict (one closest pair, or empty tensors beyond MAX_DIST).  Batched envs: tensors
+        with a leading E axis plus a boolean 'valid' (E,) instead of empty results.  body=True returns the points in
+        this quadcopter's frame, R^T (p - pos) (what Object.py:129-131 is after; as written it mis-broadcasts)."""
+        j = other.uid if not isinstance(other, int) else other
+        dist, ps, po = self.env.proximity(points=True)
+        sh = self.env._mrs.shard
+        b = lambda t: t.unsqueeze(0) if sh.E == 1 else t
+        d, a, c = b(dist)[:, self._i, j], b(ps)[:, self._i, j], b(po)[:, self._i, j]
+        if body:
+            Rm, p = b(self.env.get_ori(mat=True))[:, self._i], b(self.env.get_pos())[:, self._i]
+            a = torch.einsum('eji,ej->ei', Rm, a - p)
+            c = torch.einsum('eji,ej->ei', Rm, c - p)
+        valid = d <= MAX_DIST
+        if sh.E == 1:
+            if not bool(valid[0]):
+                return {'closest pos self': torch.zeros(0, 3), 'closest pos other': torch.zeros(0, 3), 'distance': torch.zeros(0)}
+            return {'closest pos self': a, 'closest pos other': c, 'distance': d}
+        return {'closest pos self': a, 'closest pos other': c, 'distance': d, 'valid': valid}
+
+    def get_contact_points(self, other=None, body=False):  # Object.py:100-116
+        """Objects within the contact threshold of this quadcopter (MrsParams.contact_threshold, Bullet's contact
+        breaking threshold): one point per touching object -- the closest pair.  'normal force' is not retained by the
+        fused step (its impulses live in registers): zeros.  One env only; batched envs use Environment.proximity()."""
+        sh = self.env._mrs.shard
+        if sh.E != 1:
+            raise NotImplementedError("get_contact_points returns ragged lists: with N_ENVS > 1 use env.proximity() / env.collisions()")
+        dist, ps, po = self.env.proximity(points=True)
+        thr = float(sh.params.contact_threshold)
+        d = dist[self._i].clone()
+        d[self._i] = float('inf')
+        if other is not None:
+            keep = torch.zeros_like(d, dtype=torch.bool)
+            keep[other.uid if not isinstance(other, int) else other] = True
+            d = torch.where(keep, d, torch.full_like(d, float('inf')))
+        idx = torch.nonzero(d <= thr).flatten()
+        if idx.numel() == 0:
+            return {'object': [], 'pos': torch.zeros(0, 3), 'normal force': torch.zeros(0, 3), 'distance': torch.zeros(0)}
+        pts = ps[self._i, idx]
+        if body:
+            Rm, p = self.env.get_ori(mat=True)[self._i], self.env.get_pos()[self._i]
+            pts = (pts - p) @ Rm
+        return {'object': [self.env.object_by_index(int(j)) for j in idx.tolist()], 'pos': pts,
+                'normal force': torch.zeros(idx.numel(), 3, device=pts.device), 'distance': d[idx]}
+
+    def collision(self):  # Object.py:136-137
+        c = self.env.collisions()
+        return bool(c[self._i]) if self.env._mrs.shard.E == 1 else c[:, self._i]
+
+    def get_closest_objects(self, radius):  # Object.py:140-147
+        """Objects whose bounding box overlaps pos +- radius and that are within `radius` of this quadcopter's hull
+        (the reference's own two tests; it lists the quadcopter itself too, its AABB overlaps and its distance is 0)."""
+        sh = self.env._mrs.shard
+        if sh.E != 1:
+            raise NotImplementedError("get_closest_objects returns object lists: with N_ENVS > 1 use env.proximity(max_dist=radius)")
+        dist = self.env.proximity()
+        pos = self.env.get_pos()
+        bound = float((sh.params.coll_radius ** 2 + sh.params.coll_half_len ** 2) ** 0.5)
+        out = []
+        for j in range(sh.N):
+            box = bool(((pos[j] - pos[self._i]).abs() <= radius + bound).all())
+            if box and float(dist[self._i, j]) <= radius:
+                out.append(self.env.agents[j])
+        gz = float(sh.params.ground_z)
+        if float(pos[self._i, 2]) - radius <= gz and float(dist[self._i, sh.N]) <= radius:
+            out.append(self.env.ground)
+        return out
+
+    def get_image(self, *a, **k):  # Object.py:177-195: a rasterised camera image -- GUI / rendering, out of scope
+        raise NotImplementedError("camera images are rendered by pybullet's GUI/TinyRenderer; not on the accelerated path")
+
+
+class GroundView:
+    """The plane.urdf object of env_generator('simple') (EnvCreator.py:11): static 30 x 30 x 1 m box, top face z = ground_z."""
+
+    def __init__(self, env, uid):
+        self.env, self.uid = env, int(uid)
+
+    def get_pos(self):
+        return torch.zeros(3)
+
+    def get_vel(self):
+        return torch.zeros(3)
+
+    get_angvel = get_vel
+
+    def get_ori(self, mat=False):
+        return torch.eye(3) if mat else torch.zeros(3)
+
+    def collision(self):
+        return bool(self.env.collisions(ground=True).any())
 
 
 class Environment:
@@ -92,9 +196,12 @@ class Environment:
         self._mrs = mrs
         self.sim = mrs.sim
         self.agents = [QuadView(self, i) for i in range(mrs.N_AGENTS)]
-        self.objects = []            # the ground box is implicit in MrsParams.ground_z
+        self.ground = GroundView(self, mrs.N_AGENTS)   # uid N: the index the sensor kernels report for it
+        self.objects = [self.ground]
         self.controlled = []
         self.object_dict = {a.uid: a for a in self.agents}
+        self.object_dict[self.ground.uid] = self.ground
+        self._sensor_cache = {}
         self.agent_idxs = {a: i for i, a in enumerate(self.agents)}
         self.data = {}
         self.debug_names = {}
@@ -138,6 +245,46 @@ class Environment:
                          2 * (x * y + z * w), -x * x + y * y - z * z + w * w, 2 * (y * z - x * w),
                          2 * (x * z - y * w), 2 * (y * z + x * w), -x * x - y * y + z * z + w * w], -1)
         return self._out(R.reshape(sh.E, sh.N, 3, 3).to(torch.float32))
+
+    # ------------------------------------------------------------------ batched sensors (Object.py:100-174 for all agents)
+    def object_by_index(self, j):
+        """index reported by the sensor kernels -> object: -1 None, 0..N-1 quadcopters, N the ground"""
+        return None if j < 0 else (self.ground if j == self._mrs.N_AGENTS else self.agents[j])
+
+    def _cached(self, key, fn):
+        ver = self._mrs.shard.version
+        hit = self._sensor_cache.get(key)
+        if hit is None or hit[0] != ver:
+            if len(self._sensor_cache) > 16:
+                self._sensor_cache.clear()
+            hit = self._sensor_cache[key] = (ver, fn())
+        return hit[1]
+
+    def raycast(self, offset, directions, body=True, RANGE=100.0):
+        """Object.raycast (Object.py:150-174) from every quadcopter: dict of (N,R,..) / (E,N,R,..) tensors; "object" holds
+        indices (-1 miss, j < N quadcopter j, N the ground)."""
+        o = torch.as_tensor(offset, dtype=torch.float32).reshape(-1, 3)
+        d = torch.as_tensor(directions, dtype=torch.float32).reshape(-1, 3)
+        key = ("ray", tuple(o.flatten().tolist()), tuple(d.flatten().tolist()), bool(body), float(RANGE))
+        out = self._cached(key, lambda: self._mrs.shard.raycast(o, d, body=body, RANGE=RANGE))
+        return {k: self._out(v) for k, v in out.items()}
+
+    def proximity(self, max_dist=float('inf'), points=False):
+        """Object.get_dist (Object.py:119-133) for every ordered pair: distances (N,N+1) / (E,N,N+1), column N = ground."""
+        out = self._cached(("prox", float(max_dist), bool(points)), lambda: self._mrs.shard.proximity(max_dist, points))
+        return tuple(self._out(t) for t in out) if points else self._out(out)
+
+    def collisions(self, ground=False):
+        """Object.collision (Object.py:136-137) for every quadcopter: (N,) / (E,N) bool -- something within the contact
+        threshold (a contact point exists; its distance is then < 0.04).  ground=True: only contacts with the ground."""
+        sh = self._mrs.shard
+        thr = float(sh.params.contact_threshold)
+        d = self._cached(("prox", thr, False), lambda: sh.proximity(thr, False))
+        if ground:
+            return self._out(d[..., sh.N] <= thr)
+        eye = torch.zeros(sh.N, sh.N + 1, dtype=torch.bool, device=d.device)
+        eye[torch.arange(sh.N), torch.arange(sh.N)] = True
+        return self._out((d.masked_fill(eye, float('inf')) <= thr).any(-1))
 
     def get_X(self, state_fn):  # Environment.py:84-87
         return self._mrs._obs.evaluate(state_fn)

@@ -30,6 +30,7 @@ EXPORTS = [
     "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
     "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
     "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn", "mrs_reynolds",
+    "mrs_raycast", "mrs_proximity",
 ]
 
 
@@ -91,6 +92,8 @@ def lib():
         L.mrs_spawn.argtypes = [vp, C.POINTER(MrsBuffers), C.c_uint64, C.c_int64, C.c_double,
                                 C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, vp, vp]
         L.mrs_reynolds.argtypes = [vp, vp, C.c_int, vp, vp]
+        L.mrs_raycast.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]
+        L.mrs_proximity.argtypes = [vp, C.POINTER(MrsBuffers), C.c_double, vp, vp, vp, vp]
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
@@ -158,6 +161,7 @@ class SwarmShard:
         self.pid[12:] = float("nan")          # last_vel_e / last_target_vel "attribute not created yet"
         self.status = torch.zeros(self.E, dtype=torch.int32, device=device)
         self.rpm = torch.zeros(4, self.T, dtype=torch.float32, device=device) if want_rpm else None
+        self.version = 0                      # bumped by everything that changes the state (sensor caches key on it)
         self.set_obs_fields(obs_fields)
         self.adj = torch.zeros(self.E, self.N, self.W, dtype=torch.int64, device=device)
         self.obs = None
@@ -221,6 +225,7 @@ class SwarmShard:
             ori = ori.reshape(E, N, per_agent).contiguous()
         mask = None if env_mask is None else torch.as_tensor(env_mask, device=dev).to(torch.uint8).contiguous()
         b = self._buffers()
+        self.version += 1
         _check(self.L.mrs_set_state(self.h, C.byref(b), _ptr(pos), _ptr(ori), kind, _ptr(vel), _ptr(angvel), _ptr(mask),
                                     _stream(dev)), "mrs_set_state")
 
@@ -232,6 +237,7 @@ class SwarmShard:
         pos, quat, vel, angvel = g(pos, 3), g(quat, 4), g(vel, 3), g(angvel, 3)
         mask = None if env_mask is None else torch.as_tensor(env_mask, device=dev).to(torch.uint8).contiguous()
         b = self._buffers()
+        self.version += 1
         _check(self.L.mrs_set_state_f64(self.h, C.byref(b), _ptr(pos), _ptr(quat), _ptr(vel), _ptr(angvel), _ptr(mask),
                                         _stream(dev)), "mrs_set_state_f64")
 
@@ -251,6 +257,7 @@ class SwarmShard:
             if actions.numel() != self.T * ACT_DIM[at]:
                 raise ValueError("actions has %d elements, expected (E,N,%d)" % (actions.numel(), ACT_DIM[at]))
         b = self._buffers(obs_out, adj_out)
+        self.version += 1
         cr = float(comm_range) if adj_out is not None else float("nan")
         rc = self.L.mrs_step(self.h, C.byref(b), _ptr(actions), at, self.obs_codes, self.n_obs if obs_out is not None else 0,
                              cr, _stream(self.device))
@@ -265,6 +272,7 @@ class SwarmShard:
         b = self._pb
         b.obs = obs_ptr or None
         b.adj = adj_ptr or None
+        self.version += 1
         rc = self.L.mrs_step(self.h, self._pb_ref, actions.data_ptr() if actions is not None else None, at, self.obs_codes,
                              self.n_obs if obs_ptr else 0, comm_range if adj_ptr else _NAN,
                              torch.cuda.current_stream(self.device).cuda_stream)
@@ -295,6 +303,7 @@ class SwarmShard:
         hi = (C.c_float * 3)(*[float(x) for x in ori_hi])
         mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
         b = self._buffers()
+        self.version += 1
         _check(self.L.mrs_spawn(self.h, C.byref(b), int(seed) & (2 ** 64 - 1), int(env_index_base), float(agent_radius),
                                 lo, hi, int(max_rounds), _ptr(mask), _stream(self.device)), "mrs_spawn")
 
@@ -310,6 +319,36 @@ class SwarmShard:
         _check(self.L.mrs_reynolds(self.h, _ptr(x_prev), D, _ptr(actions_out), _stream(self.device)), "mrs_reynolds")
         return actions_out
 
+    # ------------------------------------------------------------------ geometry sensors (Object.py:100-174)
+    def raycast(self, offset, directions, body=True, RANGE=100.0):
+        """Object.raycast for every quadcopter of every env: offset (3,) or (R,3), directions (3,) or (R,3).
+        Returns dict of device tensors: object (E,N,R) int32 [-1 miss, j < N quadcopter, N ground], "pos world" /
+        "pos" (E,N,R,3), dist (E,N,R)."""
+        dev = self.device
+        d = torch.as_tensor(directions, dtype=torch.float32, device=dev).reshape(-1, 3).contiguous()
+        o = torch.as_tensor(offset, dtype=torch.float32, device=dev).reshape(-1, 3)
+        o = o.expand(d.shape[0], 3).contiguous()
+        R = d.shape[0]
+        hit = torch.empty(self.E, self.N, R, dtype=torch.int32, device=dev)
+        pw = torch.empty(self.E, self.N, R, 3, dtype=torch.float32, device=dev)
+        pb = torch.empty_like(pw)
+        dist = torch.empty(self.E, self.N, R, dtype=torch.float32, device=dev)
+        b = self._buffers()
+        _check(self.L.mrs_raycast(self.h, C.byref(b), _ptr(o), _ptr(d), R, int(bool(body)), float(RANGE), _ptr(hit), _ptr(pw),
+                                  _ptr(pb), _ptr(dist), _stream(dev)), "mrs_raycast")
+        return {"object": hit, "pos world": pw, "pos": pb, "dist": dist}
+
+    def proximity(self, max_dist=float("inf"), points=False):
+        """Object.get_dist for every ordered pair: (E,N,N+1) float32 distances (column N = ground; +inf beyond max_dist),
+        plus the closest points (E,N,N+1,3) x2 if asked."""
+        dev = self.device
+        dist = torch.empty(self.E, self.N, self.N + 1, dtype=torch.float32, device=dev)
+        ps = torch.empty(self.E, self.N, self.N + 1, 3, dtype=torch.float32, device=dev) if points else None
+        po = torch.empty_like(ps) if points else None
+        b = self._buffers()
+        _check(self.L.mrs_proximity(self.h, C.byref(b), float(max_dist), _ptr(dist), _ptr(ps), _ptr(po), _stream(dev)), "mrs_proximity")
+        return (dist, ps, po) if points else dist
+
     # ------------------------------------------------------------------ views (E,N,k), zero-copy
     def view(self, t):
         k = t.shape[0]
@@ -319,5 +358,6 @@ class SwarmShard:
         return {k: getattr(self, k).clone() for k in ("pos", "quat", "vel", "angvel", "pid")}
 
     def load_state_dict(self, sd):
+        self.version += 1
         for k in ("pos", "quat", "vel", "angvel", "pid"):
             getattr(self, k).copy_(sd[k])

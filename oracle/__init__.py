@@ -66,8 +66,8 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/libmrs_oracle.so with gcc (make)."""
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mrs_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("mrs_oracle.c", "mrs_sensors.c", "mrs_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libmrs_oracle.so"])
     return _LIB_PATH
 
@@ -102,6 +102,10 @@ def lib():
         _lib.orc_integrate.argtypes = [PP, dp, dp, dp, dp, dp, dp]
         _lib.orc_step_full.argtypes = [PP, C.c_int, C.c_int, dp, dp, dp, dp, C.c_void_p, fp, C.c_int, C.c_int,
                                        C.c_double, fp, fp, C.c_int]
+        ip = C.POINTER(C.c_int)
+        _lib.orc_raycast.argtypes = [PP, C.c_int, dp, dp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, ip, fp, fp, fp]
+        _lib.orc_closest.argtypes = [PP, C.c_int, dp, dp, C.c_int, dp, dp, dp]
+        _lib.orc_proximity.argtypes = [PP, C.c_int, dp, dp, dp]
     return _lib
 
 
@@ -231,6 +235,40 @@ def reynolds(x_prev):
     out = np.zeros((E, N, 3), np.float32)
     lib().orc_reynolds(E, N, D, _f(x), _f(out))
     return out
+
+
+def raycast(pos, quat, agent, offset, directions, body=True, RANGE=100.0, params=None):
+    """Object.raycast of one agent of one env: pos (N,3), quat (N,4) float64; offset / directions (R,3) float32."""
+    p = params or default_params()
+    pos, quat = f64(pos), f64(quat)
+    N = pos.shape[0]
+    d = f32(directions).reshape(-1, 3)
+    o = np.ascontiguousarray(np.broadcast_to(f32(offset).reshape(-1, 3), d.shape))
+    n = d.shape[0]
+    obj = np.zeros(n, np.int32)
+    pw, pb, dist = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    lib().orc_raycast(C.byref(p), N, _d(pos), _d(quat), int(agent), _f(o), _f(d), n, int(bool(body)), float(RANGE),
+                      obj.ctypes.data_as(C.POINTER(C.c_int)), _f(pw), _f(pb), _f(dist))
+    return {"object": obj, "pos world": pw, "pos": pb, "dist": dist}
+
+
+def closest(pos, quat, agent, params=None):
+    """Object.get_dist of one agent against every quadcopter and the ground (index N) of one env."""
+    p = params or default_params()
+    pos, quat = f64(pos), f64(quat)
+    N = pos.shape[0]
+    dist, ps, po = np.zeros(N + 1), np.zeros((N + 1, 3)), np.zeros((N + 1, 3))
+    lib().orc_closest(C.byref(p), N, _d(pos), _d(quat), int(agent), _d(dist), _d(ps), _d(po))
+    return {"distance": dist, "closest pos self": ps, "closest pos other": po}
+
+
+def proximity(pos, quat, params=None):
+    p = params or default_params()
+    pos, quat = f64(pos), f64(quat)
+    N = pos.shape[0]
+    D = np.zeros((N, N + 1))
+    lib().orc_proximity(C.byref(p), N, _d(pos), _d(quat), _d(D))
+    return D
 
 
 def integrate(params, pos, quat, vel, angvel, force_body, torque_body):

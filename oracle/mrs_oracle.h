@@ -129,6 +129,15 @@ void orc_step_full(const OrcParams *p, int E, int N, double *pos, double *quat, 
 void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3],
                    const double force_body[3], const double torque_body[3]);
 
+/* ---- geometry sensors (mrs_sensors.c; Object.py:100-174 against the analytic scene; PARITY UNPINNED, see there) ---- */
+/* Object.raycast (Object.py:150-174) for agent `self` of ONE env: hit_obj -1 none / 0..N-1 quadcopter / N ground */
+void orc_raycast(const OrcParams *p, int N, const double *pos, const double *quat, int self, const float *offset,
+                 const float *dirs, int n_rays, int body, float range, int *hit_obj, float *pos_world, float *pos_body, float *dist);
+/* Object.get_dist (Object.py:119-133) of agent `self` against quadcopters 0..N-1 and the ground (index N) */
+void orc_closest(const OrcParams *p, int N, const double *pos, const double *quat, int self, double *dist, double *pself, double *pother);
+/* all rows at once: D[N][N+1] */
+void orc_proximity(const OrcParams *p, int N, const double *pos, const double *quat, double *D);
+
 #ifdef __cplusplus
 }
 #endif

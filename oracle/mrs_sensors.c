@@ -41,7 +41,6 @@ static void qmat(const double q[4], double R[9])
     R[3] = xy + wz; R[4] = 1 - (xx + zz); R[5] = yz - wx;
     R[6] = xz - wy; R[7] = yz + wx; R[8] = 1 - (xx + yy);
 }
-static v3 mv(const double R[9], v3 a) { return V(R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z, R[6] * a.x + R[7] * a.y + R[8] * a.z); }
 static v3 mtv(const double R[9], v3 a) { return V(R[0] * a.x + R[3] * a.y + R[6] * a.z, R[1] * a.x + R[4] * a.y + R[7] * a.z, R[2] * a.x + R[5] * a.y + R[8] * a.z); }
 
 /* ------------------------------------------------------------------------------------------------ rays */
@@ -244,14 +243,29 @@ static double gjk_cyl_cyl(const Cyl *A, const Cyl *B, v3 *pa, v3 *pb)
         const v3 sa = cyl_support(A, mul(-1, v)), sb = cyl_support(B, v), w = sub(sa, sb);
         const double vv = dot(v, v);
         if (s.n > 0 && vv - dot(v, w) <= 1e-14 * vv + 1e-30) break; /* no closer support point: v is the answer */
+        int dup = 0; /* a support point already in the simplex: converged to rounding */
+        for (int k = 0; k < s.n; ++k) dup |= (s.w[k].x == w.x && s.w[k].y == w.y && s.w[k].z == w.z);
+        if (dup) break;
+        const Simplex prev = s;
         s.w[s.n] = w; s.a[s.n] = sa; s.b[s.n] = sb; s.n++;
         int inside = 0;
         if (s.n == 1) s.l[0] = 1;
         else if (s.n == 2) closest_segment(&s);
         else if (s.n == 3) closest_triangle(&s);
         else inside = closest_tetra(&s);
-        if (inside) { *pa = *pb = mul(0.5, add(sa, sb)); return 0.0; }
-        v = simplex_point(&s);
+        if (inside) { /* origin = sum l_i w_i inside the tetrahedron => sum l_i a_i = sum l_i b_i lies in both bodies */
+            const v3 e1 = sub(s.w[1], s.w[0]), e2 = sub(s.w[2], s.w[0]), e3 = sub(s.w[3], s.w[0]), o = mul(-1, s.w[0]);
+            const double vol = dot(e1, cross(e2, e3));
+            double l1 = dot(o, cross(e2, e3)) / vol, l2 = dot(e1, cross(o, e3)) / vol, l3 = dot(e1, cross(e2, o)) / vol;
+            if (!(fabs(vol) > 0)) { l1 = l2 = l3 = 0.25; }
+            const double l0 = 1 - l1 - l2 - l3;
+            const v3 x = add(add(mul(l0, s.a[0]), mul(l1, s.a[1])), add(mul(l2, s.a[2]), mul(l3, s.a[3])));
+            *pa = *pb = x;
+            return 0.0;
+        }
+        const v3 vn = simplex_point(&s);
+        if (prev.n > 0 && dot(vn, vn) >= vv) { s = prev; break; } /* sliver simplex on a curved rim: no progress, keep the best */
+        v = vn;
         if (dot(v, v) < 1e-24) break;
     }
     v3 a = V(0, 0, 0), b = V(0, 0, 0);
@@ -279,7 +293,7 @@ static Cyl make_cyl(const OrcParams *p, const double *pos, const double *quat)
 static double cyl_ground(const OrcParams *p, const Cyl *c, v3 *pc, v3 *pg)
 {
     const double az = c->a.z;
-    v3 low = add(c->c, mul(az >= 0 ? -c->hl : c->hl, c->a));
+    v3 low = add(c->c, mul(az > 1e-12 ? -c->hl : (az < -1e-12 ? c->hl : 0.0), c->a)); /* on edge: the middle of the lowest line */
     v3 rad = sub(V(0, 0, -1), mul(-az, c->a)); /* -z minus its axial part */
     const double n = len(rad);
     if (n > 1e-9) low = add(low, mul(c->rc / n, rad));

@@ -466,8 +466,42 @@ def gen_F7(out):
         key = "N%d_D%d" % (N, D)
         data[key + "_Xs"] = Xs
         data[key + "_actions"] = act.numpy().astype(np.float32)
+    # K > 1 (Reynolds.py:89-97 aggregate hops 2..K, but Reynolds_Node.py:30 reads hops 0 and 1 only)
+    for N, B, D, K in ((12, 4, 6, 2), (12, 3, 9, 3)):
+        Xs = np.concatenate([rng.normal(0, 1.5, (B, N, 3, K + 1)), rng.normal(0, 0.7, (B, N, D - 3, K + 1))], 2).astype(np.float32)
+        model = Reynolds(N=N, D=D, K=K, OUT_DIM=3)
+        with torch.no_grad():
+            act = model.forward(None, torch.from_numpy(Xs.copy()))
+        key = "N%d_D%d_K%d" % (N, D, K)
+        data[key + "_Xs"] = Xs
+        data[key + "_actions"] = act.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(out, "F7_reynolds.npz"), **data)
     return sorted(k for k in data if k.endswith("_Xs"))
+
+
+def gen_F8(out):
+    """Flocking metrics of the reference's analytics (examples/simulating_data/helper/MRSAnalytics.py:13-101) on
+    synthetic episode tensors X (episodes, length, N, 6), incl. an episode with two coincident agents (separation
+    masks zero distances with inf, :70) -- the class as it is, fed through the `data.get_episodes()` it expects."""
+    import torch
+    sys.path.insert(0, os.path.join(REF, "examples", "simulating_data"))
+    _stub("gym")
+    from helper.MRSAnalytics import MRSAnalytics
+    rng = np.random.default_rng(88)
+    data = {}
+    for N, EP, L in ((3, 2, 5), (12, 3, 7), (64, 2, 4)):
+        X = np.concatenate([rng.normal(0, 1.5, (EP, L, N, 3)), rng.normal(0, 0.7, (EP, L, N, 3))], -1).astype(np.float32)
+        X[0, 0, 1, :3] = X[0, 0, 0, :3]
+        an = MRSAnalytics(types.SimpleNamespace(get_episodes=lambda X=X: {"X": torch.from_numpy(X.copy())}))
+        key = "N%d" % N
+        data[key + "_X"] = X
+        for name in ("separation", "cohesion", "dist_to_leader", "vel_stddev", "vel_mag", "vel_leader_alignment"):
+            data[key + "_" + name] = getattr(an, name)().numpy()
+        data[key + "_cohesion_noleader"] = an.cohesion(exclude_leader=True).numpy()
+        for name in ("separation_avg", "cohesion_avg", "vel_stddev_avg", "vel_mag_avg", "vel_leader_alignment_avg"):
+            data[key + "_" + name] = np.float32(getattr(an, name)())
+    np.savez_compressed(os.path.join(out, "F8_flock_metrics.npz"), **data)
+    return sorted(k for k in data if k.endswith("_X"))
 
 
 def main():
@@ -481,6 +515,10 @@ def main():
     if args.only == "F7":
         print("F7", gen_F7(args.out))
         return
+    if args.only == "F8":
+        import_reference(FakeBullet())
+        print("F8", gen_F8(args.out))
+        return
     mrsgym = import_reference(FakeBullet())
     print("F1 anchor", gen_F1(mrsgym, args.out))
     print("F2 nnls-branch fraction", gen_F2(mrsgym, args.out))
@@ -489,13 +527,15 @@ def main():
     gen_F5(mrsgym, args.out); print("F5 done")
     print("F6", gen_F6(args.out))
     print("F7", gen_F7(args.out))
+    print("F8", gen_F8(args.out))
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write("Golden fixtures generated by tools/gen_golden.py from the reference's own Python\n"
                 "(numpy %s, scipy %s).  Data only: inputs and expected outputs.\n"
                 "F1 QuadControl cascade, F2 nnlsRPM, F3 MRS.calc_A, F4 history deques, F5 spawn,\n"
                 "F6 full MRS.step() trajectories with pybullet replaced by the build's own oracle\n"
                 "integrator (pins everything except the Bullet integrator/contact: parity unpinned there),\n"
-                "F7 the Reynolds flocking expert of examples/simulating_data (forward_batch, D=6/9, K=1).\n"
+                "F7 the Reynolds flocking expert of examples/simulating_data (forward_batch, D=6/9, K=1..3),\n"
+                "F8 the flocking metrics of examples/simulating_data/helper/MRSAnalytics.py.\n"
                 % (np.__version__, scipy.__version__))
 
 
