@@ -185,6 +185,17 @@ int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offset, const fl
  * collision() (:136-137), get_contact_points (:100-116) and get_closest_objects (:140-147) are thresholds on this. */
 int mrs_proximity(MrsHandle *h, const MrsBuffers *b, double max_dist, float *dist, float *p_self, float *p_other, void *stream);
 
+/* ---- flocking metrics of the reference's analytics: examples/simulating_data/helper/
+ * MRSAnalytics.py:36-101 over M frames X (M,N,D) float32, D >= 6 = cat(pos, vel, ...) (one frame = one step of one
+ * episode; Trainer.get_episodes' NaN padding propagates as in torch).  Every output is optional (NULL = skip):
+ *   separation (M,N)      distance to the closest other agent, coincident agents masked (:61-72)
+ *   cohesion (M), cohesion_noleader (M)   largest pairwise distance, with / without agent 0 (:82-93)
+ *   dist_to_leader (M)    |mean(pos[1:]) - pos[0]| (:95-101)
+ *   vel_stddev (M)        sqrt(det(sum_i (v_i - vbar)(v_i - vbar)^T)) (:44-53)
+ * No handle: the call touches no env state; runs on the current device of `stream`. */
+int mrs_flock_metrics(const float *X, int n_frames, int n_agents, int D, float *separation, float *cohesion,
+                      float *cohesion_noleader, float *dist_to_leader, float *vel_stddev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

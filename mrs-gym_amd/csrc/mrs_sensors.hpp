@@ -331,6 +331,93 @@ __global__ __launch_bounds__(256) void k_proximity(const ProxArgs S)
 
 } // namespace mrs_sense
 
+
+// ---- flocking metrics of the reference's analytics (examples/simulating_data/helper/MRSAnalytics.py:36-101) as device
+// reductions: one workgroup per frame (episode, time step), positions and velocities of its N agents staged in LDS.
+namespace mrs_metrics {
+struct MetricArgs {
+    const float *X; // (M,N,D) frames, D >= 6 = cat(pos, vel, ...)
+    float *sep, *coh, *coh_nl, *lead, *vstd;
+    int M, N, D;
+};
+__global__ __launch_bounds__(256) void k_flock_metrics(const MetricArgs S)
+{
+    extern __shared__ float4 lds[]; // [N] positions, [N] velocities
+    __shared__ unsigned s_max[2];
+    const int f = blockIdx.x, N = S.N;
+    float4 *P = lds, *V = lds + N;
+    const float *x = S.X + (size_t)f * N * S.D;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        P[j] = make_float4(x[j * S.D], x[j * S.D + 1], x[j * S.D + 2], 0.f);
+        V[j] = make_float4(x[j * S.D + 3], x[j * S.D + 4], x[j * S.D + 5], 0.f);
+    }
+    if (threadIdx.x < 2) s_max[threadIdx.x] = 0u;
+    __syncthreads();
+    // separation (:61-72): distance to the closest OTHER position, zero distances masked with inf (:70);
+    // cohesion (:82-93): the largest pairwise distance (all agents / without the leader, agent 0).
+    // codist = (posi - posj).norm(dim=3): float32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
+    float mx = 0.f, mx_nl = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float4 pi = P[i];
+        float mn = INFINITY;
+        for (int j = 0; j < N; ++j) {
+            const float4 pj = P[j];
+            const float dx = mrs::f32sub(pj.x, pi.x), dy = mrs::f32sub(pj.y, pi.y), dz = mrs::f32sub(pj.z, pi.z);
+            const float d = mrs::f32sqrt(mrs::f32fma(dz, dz, mrs::f32fma(dy, dy, mrs::f32mul(dx, dx))));
+            mn = fminf(mn, d == 0.f ? INFINITY : d);          // NaN frames (padding of short episodes) stay NaN-free here: fminf drops NaN
+            mx = (d > mx || d != d) ? d : mx;                  // torch.max propagates NaN
+            if (i > 0 && j > 0) mx_nl = (d > mx_nl || d != d) ? d : mx_nl;
+        }
+        if (S.sep) {
+            // a frame of NaNs (Trainer.get_episodes pads short episodes with NaN): every distance is NaN, NaN == 0 is false,
+            // min over NaNs is NaN in torch
+            S.sep[(size_t)f * N + i] = (pi.x != pi.x) ? NAN : mn;
+        }
+    }
+    // positive floats order like their bit patterns; NaN (0x7fc00000) is larger than every finite pattern => propagates
+    atomicMax(&s_max[0], __float_as_uint(mx));
+    atomicMax(&s_max[1], __float_as_uint(mx_nl));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (S.coh) S.coh[f] = __uint_as_float(s_max[0]);
+        if (S.coh_nl) S.coh_nl[f] = __uint_as_float(s_max[1]);
+        if (S.lead) { // :95-101  | mean(pos[1:]) - pos[0] |
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int j = 1; j < N; ++j) { sx += P[j].x; sy += P[j].y; sz += P[j].z; }
+            const float n1 = (float)(N - 1);
+            const float dx = sx / n1 - P[0].x, dy = sy / n1 - P[0].y, dz = sz / n1 - P[0].z;
+            S.lead[f] = sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+        if (S.vstd) { // :44-53  sqrt(det(sum_i (v_i - vbar)(v_i - vbar)^T))
+            double m[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < N; ++j) { m[0] += V[j].x; m[1] += V[j].y; m[2] += V[j].z; }
+            // vel_avg and the differences are float32 tensors upstream
+            const float ax = (float)(m[0] / N), ay = (float)(m[1] / N), az = (float)(m[2] / N);
+            for (int j = 0; j < N; ++j) {
+                const double dx = (double)(V[j].x - ax), dy = (double)(V[j].y - ay), dz = (double)(V[j].z - az);
+                c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+            }
+            const double det = c[0] * (c[3] * c[5] - c[4] * c[4]) - c[1] * (c[1] * c[5] - c[4] * c[2]) + c[2] * (c[1] * c[4] - c[3] * c[2]);
+            S.vstd[f] = (float)sqrt(det);
+        }
+    }
+}
+} // namespace mrs_metrics
+
+extern "C" int mrs_flock_metrics(const float *X, int n_frames, int n_agents, int D, float *separation, float *cohesion,
+                                 float *cohesion_noleader, float *dist_to_leader, float *vel_stddev, void *stream)
+{
+    if (!X || n_frames < 0 || n_agents < 1 || D < 6) return fail(MRS_E_ARG, "mrs_flock_metrics: bad argument (X, n_frames >= 0, n_agents >= 1, D >= 6)");
+    if (n_frames == 0) return 0;
+    if ((size_t)n_agents * 2 * sizeof(float4) > 64 * 1024) return fail(MRS_E_ARG, "mrs_flock_metrics: n_agents too large for one workgroup's LDS");
+    mrs_metrics::MetricArgs S;
+    S.X = X; S.sep = separation; S.coh = cohesion; S.coh_nl = cohesion_noleader; S.lead = dist_to_leader; S.vstd = vel_stddev;
+    S.M = n_frames; S.N = n_agents; S.D = D;
+    hipLaunchKernelGGL(mrs_metrics::k_flock_metrics, dim3(n_frames), dim3(256), (size_t)n_agents * 2 * sizeof(float4), (hipStream_t)stream, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_flock_metrics launch");
+}
+
 extern "C" int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offset, const float *directions, int n_rays, int body,
                            float range, int32_t *hit_obj, float *pos_world, float *pos_body, float *dist, void *stream)
 {

@@ -11,6 +11,7 @@ try:
     from .mrs import MRS, make  # noqa: F401
     from .reynolds import Reynolds  # noqa: F401
     from .rollout import RolloutLog  # noqa: F401
-    __all__ += ["MRS", "make", "Reynolds", "RolloutLog"]
+    from .analytics import MRSAnalytics  # noqa: F401
+    __all__ += ["MRS", "make", "Reynolds", "RolloutLog", "MRSAnalytics"]
 except ImportError:  # pragma: no cover - during bootstrap only
     pass

@@ -30,7 +30,7 @@ EXPORTS = [
     "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
     "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
     "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn", "mrs_reynolds",
-    "mrs_raycast", "mrs_proximity",
+    "mrs_raycast", "mrs_proximity", "mrs_flock_metrics",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.mrs_reynolds.argtypes = [vp, vp, C.c_int, vp, vp]
         L.mrs_raycast.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]
         L.mrs_proximity.argtypes = [vp, C.POINTER(MrsBuffers), C.c_double, vp, vp, vp, vp]
+        L.mrs_flock_metrics.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
@@ -127,6 +128,23 @@ def _ptr(t):
 
 def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def flock_metrics(X, want=("separation", "cohesion", "cohesion_noleader", "dist_to_leader", "vel_stddev")):
+    """mrs_flock_metrics on frames X (..., N, D>=6) float32 (device): dict of tensors shaped like the leading axes."""
+    if not X.is_cuda:
+        raise MrsNativeError("flock_metrics runs on the GPU only (X is on %s)" % X.device)
+    X = X.to(torch.float32).contiguous()
+    lead_shape, N, D = X.shape[:-2], X.shape[-2], X.shape[-1]
+    M = int(X.numel() // (N * D)) if N * D else 0
+    out = {}
+    for k in want:
+        out[k] = torch.empty(lead_shape + ((N,) if k == "separation" else ()), dtype=torch.float32, device=X.device)
+    g = lambda k: _ptr(out[k]) if k in out else None
+    with torch.cuda.device(X.device):
+        _check(lib().mrs_flock_metrics(_ptr(X), M, N, D, g("separation"), g("cohesion"), g("cohesion_noleader"), g("dist_to_leader"),
+                                       g("vel_stddev"), _stream(X.device)), "mrs_flock_metrics")
+    return out
 
 
 class SwarmShard:

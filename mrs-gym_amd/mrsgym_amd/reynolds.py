@@ -7,7 +7,9 @@ ITS input layout `Xs: (batch, N, D, K+1)` (Reynolds.py:80-82; that is the README
 returns (K+1, N, D), MRS.py:99).  `forward_stack(Xk)` takes this library's stack `(E, K+1, N, D)` instead, and
 `from_env(env)` reads slot 1 of the env's history ring in place (no copy).  As in the reference, the adjacency
 argument is ignored (forward_batch substitutes ones - eye, Reynolds.py:83) and the states of the PREVIOUS step
-are used (:87).  Only K = 1 -- the configuration of the reference's own caller -- is implemented.
+are used (:87).  Any K >= 1: forward_batch aggregates hops 2..K (Reynolds.py:89-97), but its controller reads hops
+0 and 1 only (`Z[..., 1] - Z[..., 0]`, Reynolds_Node.py:30) and of those the first six state components, so the
+action is a function of X(t-1) alone whatever K is (tests/golden/F7 holds K = 2 and K = 3 outputs of the reference).
 """
 import torch
 
@@ -16,8 +18,8 @@ from . import native
 
 class Reynolds:
     def __init__(self, N, D, K=1, OUT_DIM=3, device="cuda"):
-        if K != 1 or OUT_DIM != 3:
-            raise NotImplementedError("Reynolds: only K=1, OUT_DIM=3 (gen_data.py:33) is on the accelerated path")
+        if K < 1 or OUT_DIM != 3:
+            raise NotImplementedError("Reynolds: K >= 1 and OUT_DIM = 3 (Reynolds_Node.py:26-38 returns 3-vectors)")
         if D < 6:
             raise ValueError("Reynolds: D must be >= 6 (rel_state_size, Reynolds.py:15)")
         self.N, self.D, self.K, self.OUT_DIM = int(N), int(D), int(K), int(OUT_DIM)
@@ -49,6 +51,8 @@ class Reynolds:
         Xk = torch.as_tensor(Xk)
         if Xk.dim() == 3:
             Xk = Xk.unsqueeze(0)
+        if Xk.shape[1] < 2:
+            raise ValueError("forward_stack needs at least the slices t and t-1 (K_HOPS >= 1)")
         x_prev = Xk[:, 1].to(device=self.device, dtype=torch.float32).contiguous()
         return self._shard(x_prev.shape[0]).reynolds(x_prev)
 

@@ -78,6 +78,34 @@ class RolloutLog:
                 hist["context"].append({})
         return {"history": hist, "iter": 0, "sample_weights": torch.tensor([]), "sample_idxs": []}
 
+    def get_episodes(self):
+        """Trainer.get_episodes (Trainer.py:186-207): every episode of every env as one row, padded with NaN to the longest:
+        {"X": (episodes, max_len, N, D), "A": (episodes, max_len, N, N), "expert": (episodes, max_len, N, out)} on the device.
+        An episode ends with the sample whose `done` is set; the last logged sample closes its env's open episode."""
+        T = self.t
+        done = self.done[:T].t().clone()                         # (E,T)
+        if T:
+            done[:, -1] = True
+        dn = done.cpu()
+        spans = []
+        for e in range(self.E):
+            start = 0
+            for t in range(T):
+                if bool(dn[e, t]):
+                    spans.append((e, start, t + 1))
+                    start = t + 1
+        L = max((b - a for _, a, b in spans), default=0)
+        nan = float("nan")
+        X = torch.full((len(spans), L, self.N, self.D), nan, device=self.device)
+        A = torch.full((len(spans), L, self.N, self.N), nan, device=self.device)
+        ex = torch.full((len(spans), L, self.N, self.expert.shape[-1]), nan, device=self.device)
+        dense = self.dense_A(0, T) if T else None
+        for k, (e, a, b) in enumerate(spans):
+            X[k, :b - a] = self.X[a:b, e]
+            A[k, :b - a] = dense[a:b, e]
+            ex[k, :b - a] = self.expert[a:b, e]
+        return {"X": X, "A": A, "expert": ex}
+
     def save_trainer(self, path):
         data = self.trainer_dict()
         with open(path, "wb") as fp:

@@ -361,15 +361,16 @@ def test_reynolds_expert_kernel(golden_dir):
         if not k.endswith("_Xs"):
             continue
         Xs, want = d[k], d[k[:-3] + "_actions"]
-        B, N, D, _ = Xs.shape
-        model = mrsgym_amd.Reynolds(N=N, D=D, K=1, OUT_DIM=3)
+        B, N, D, K1 = Xs.shape
+        model = mrsgym_amd.Reynolds(N=N, D=D, K=K1 - 1, OUT_DIM=3)
         got = model.forward(None, torch.from_numpy(Xs)).cpu().numpy()
         assert np.array_equal(got, oracle.reynolds(Xs[..., 1])), k
         assert np.abs(got - want).max() < 2e-6, k
         stack = torch.from_numpy(np.ascontiguousarray(Xs.transpose(0, 3, 1, 2)))       # (B, K+1, N, D)
         assert np.array_equal(model.forward_stack(stack).cpu().numpy(), got)
+    # K > 1: the reference's controller reads hops 0 and 1 only (Reynolds_Node.py:30): covered by the K2 / K3 fixtures above
     with pytest.raises(NotImplementedError):
-        mrsgym_amd.Reynolds(N=4, D=6, K=2)
+        mrsgym_amd.Reynolds(N=4, D=6, K=0)
     # closed loop: the expert drives a small flock through the Gym surface, reading X(t-1) from the ring in place
     E, N = 3, 12
     pos, eul = grid_spawn(E, N, seed=2)
@@ -383,6 +384,50 @@ def test_reynolds_expert_kernel(golden_dir):
         assert float(a.norm(dim=-1).max()) <= 1.0 + 1e-6
         X, r, done, info = env.step(a)
     assert torch.isfinite(X).all()
+
+
+def test_flocking_metrics_match_the_reference_analytics(golden_dir):
+    """mrs_flock_metrics / mrsgym_amd.MRSAnalytics against the reference's own MRSAnalytics outputs (tests/golden/F8,
+    generated from examples/simulating_data/helper/MRSAnalytics.py:13-101).  separation and cohesion are float32
+    norms + min/max: bit-exact; the means (torch's own summation order) and the determinant to 1e-5 relative."""
+    import mrsgym_amd
+    d = np.load(os.path.join(golden_dir, "F8_flock_metrics.npz"))
+    n = 0
+    for key in ("N3", "N12", "N64"):
+        X = torch.from_numpy(d[key + "_X"]).cuda()
+        an = mrsgym_amd.MRSAnalytics(X)
+        assert (an.num_episodes, an.episode_length, an.N) == tuple(X.shape[:3])
+        for name in ("separation", "cohesion"):
+            got = getattr(an, name)().cpu().numpy()
+            assert got.shape == d[key + "_" + name].shape
+            assert np.array_equal(got, d[key + "_" + name]), (key, name, np.abs(got - d[key + "_" + name]).max())
+        assert np.array_equal(an.cohesion(exclude_leader=True).cpu().numpy(), d[key + "_cohesion_noleader"])
+        for name, tol in (("dist_to_leader", 1e-6), ("vel_stddev", 1e-5), ("vel_mag", 1e-6), ("vel_leader_alignment", 1e-6)):
+            if name == "vel_stddev" and key == "N3":
+                continue    # three velocities minus their mean span a plane: the determinant is 0 up to rounding noise (the reference's float32 LU returns 1e-5 or NaN)
+            got = getattr(an, name)().cpu().numpy()
+            np.testing.assert_allclose(got, d[key + "_" + name], rtol=tol, atol=tol, err_msg=key + " " + name)
+        for name in ("separation_avg", "cohesion_avg", "vel_stddev_avg", "vel_mag_avg", "vel_leader_alignment_avg"):
+            if (name == "vel_stddev_avg" and key == "N3") or not np.isfinite(d[key + "_" + name]):
+                continue
+            assert abs(float(getattr(an, name)()) - float(d[key + "_" + name])) < 1e-5 * max(1.0, abs(float(d[key + "_" + name])))
+        n += 1
+    assert n == 3
+    # NaN-padded short episodes (Trainer.get_episodes) propagate like torch: that frame's metrics are NaN, the others untouched
+    X = torch.from_numpy(d["N12_X"]).cuda().clone()
+    ref = mrsgym_amd.MRSAnalytics(X.clone())
+    X[1, -2:] = float("nan")
+    an = mrsgym_amd.MRSAnalytics(X)
+    assert torch.isnan(an.cohesion()[1, -2:]).all() and torch.isnan(an.separation()[1, -2:]).all()
+    assert torch.equal(an.cohesion()[0], ref.cohesion()[0]) and torch.equal(an.separation()[1, :-2], ref.separation()[1, :-2])
+    # straight from a rollout log of the vectorised data generator
+    log = mrsgym_amd.RolloutLog(2, 12, 6, capacity=7)
+    for t in range(7):
+        log.set_state(torch.zeros(2, 12, 1, dtype=torch.int64, device="cuda"), X[:2, t], done=torch.tensor([t == 3, False]))
+    ep = log.get_episodes()
+    assert ep["X"].shape == (3, 7, 12, 6)                     # env 0: 4 + 3 steps, env 1: one episode of 7
+    an = mrsgym_amd.MRSAnalytics(log)
+    assert an.separation().shape == (3, 7, 12) and torch.isnan(an.cohesion()[0, 4:]).all() and torch.isfinite(an.cohesion()[2, :5]).all()
 
 
 def test_data_generation_loop_like_the_reference_example():

@@ -174,4 +174,4 @@ def test_F7_reynolds_expert(golden_dir):
         assert np.abs(got - want).max() < 2e-6, k
         assert np.array_equal(got == 0, want == 0), k          # the NaN -> 0 rows coincide
         n += 1
-    assert n == 4
+    assert n == 6      # four K = 1 cases + the K = 2 and K = 3 cases (the controller reads hops 0 and 1 only, Reynolds_Node.py:30)
