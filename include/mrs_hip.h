@@ -58,6 +58,7 @@ extern "C" {
 /* status bits written to MrsBuffers.status[env] */
 #define MRS_STATUS_NAN_ACTION 1u /* MRS.py:247-248: the env's step was skipped, state untouched */
 #define MRS_STATUS_SPAWN_FAIL 2u /* rejection sampling hit its iteration bound (MRS.py:137-153 would spin forever) */
+#define MRS_STATUS_SPAWN_MORE 4u /* mrs_spawn_from ran out of candidate rounds: draw more and call again with resume = 1 */
 
 /* Scene + model constants.  Filled by mrs_params_default from the values the
  * reference parses out of cf2x.urdf / plane.urdf (Quadcopter.read_attributes, Quadcopter.py:119-150)
@@ -155,6 +156,15 @@ int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int
  * Writes pos/quat, zeroes vel/angvel. */
 int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64_t env_index_base, double agent_radius,
               const float ori_lo[3], const float ori_hi[3], int max_rounds, const uint8_t *env_mask, void *stream);
+
+/* MRS.generate_start_pos (MRS.py:127-154) for a USER distribution (README.md:71-74: START_POS as a torch distribution,
+ * per-agent (3,) or joint (N,3) samples): the caller draws the samples -- candidates (E, n_rounds, N, 3) float32, round
+ * r = what every agent would receive if re-sampled in round r (per-agent and joint draws look the same here) -- and the
+ * greedy rejection of the most-colliding agents (:137-151, torch.mode = lowest index among the most frequent) runs on
+ * the device, one workgroup per env.  Writes positions only.  Envs that use up their rounds without a collision-free
+ * layout are flagged MRS_STATUS_SPAWN_MORE; call again with fresh candidates, resume = 1 and those envs in env_mask. */
+int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *candidates, int n_rounds, int resume, double agent_radius,
+                   const uint8_t *env_mask, void *stream);
 
 /* A caller of the path, fused: the Reynolds flocking expert the reference's data generator
  * drives the env with -- examples/simulating_data/helper/Reynolds.py:80-110 (forward_batch) with the controller

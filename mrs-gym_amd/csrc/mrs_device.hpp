@@ -514,6 +514,28 @@ MRS_DEV float downwash_mag(float rx, float ry, float adz, const DownwashConst &c
     const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf((d2 * rb) * rb, -0.5f * 1.44269504088896341f, c.lg_alpha));
     return (adz > 0.f && d2 < 100.f) ? -((rdz * rdz) * ex) : 0.f;
 }
+// The same term with every rounding pinned (no compiler-chosen contraction) and dxy^2 handed in: the N = 64 kernels
+// evaluate a pair either at the start of a step or -- carried over -- at the end of the previous one, inside the
+// adjacency loop that forms dxy^2 anyway; both places must produce the same bits.
+MRS_DEV float downwash_mag2(float d2, float adz, float dw2, float dw3, float lg_alpha)
+{
+    const float rdz = __builtin_amdgcn_rcpf(adz);
+    const float rb = __builtin_amdgcn_rcpf(__builtin_fmaf(dw2, adz, dw3));
+    const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf(f32mul(f32mul(d2, rb), rb), -0.5f * 1.44269504088896341f, lg_alpha));
+    return (adz > 0.f && d2 < 100.f) ? -f32mul(f32mul(rdz, rdz), ex) : 0.f;
+}
+// The three coefficients of the pair term, pinned in vector registers for the duration of a pair loop: as kernel
+// arguments they would otherwise be re-read from the argument segment (s_load + wait) inside every pair once the
+// scalar registers run short, and moved to a VGPR per use (a VOP3 takes one SGPR).
+struct DownwashRegs {
+    float dw2, dw3, lg;
+};
+MRS_DEV DownwashRegs downwash_regs(const DownwashConst &c)
+{
+    DownwashRegs r = {c.dw2, c.dw3, c.lg_alpha};
+    asm volatile("" : "+v"(r.dw2), "+v"(r.dw3), "+v"(r.lg));
+    return r;
+}
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)
 {
     const float dxy = f32sqrt(f32add(f32mul(rx, rx), f32mul(ry, ry))); // np.linalg.norm(rel[:2])
@@ -528,115 +550,6 @@ MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1,
         f = -f32mul(alpha, ex);
     }
     return f;
-}
-
-// Ground contact, the build's own model (DESIGN.md "Row G"): 8 body-fixed rim points of the collision
-// cylinder against z = ground_z, Bullet-style velocity-level rhs, sequential impulses with a friction
-// pyramid along world x/y -- the algorithm of oracle/mrs_oracle.c:contact_solve.
-//
-// Register-only formulation: every contact normal is +z and the friction axes are x,y, so the
-// effective mass of direction d at lever r is 1/(1/m + u^T Iw u) with u = r x d and
-// Iw = R diag(1/I) R^T (6 doubles, computed once); impulses apply as w += Iw (r x imp).  The 8-point
-// loop is fully unrolled so the accumulated impulses are statically indexed registers (kept in
-// float32: 24 VGPRs, no scratch, no LDS); nothing is recomputed through pointers to memory.
-struct Sym3 {
-    double xx, xy, xz, yy, yz, zz;
-};
-MRS_DEV V3 symmul(const Sym3 &S, V3 u)
-{
-    return V3{S.xx * u.x + S.xy * u.y + S.xz * u.z, S.xy * u.x + S.yy * u.y + S.yz * u.z, S.xz * u.x + S.yz * u.y + S.zz * u.z};
-}
-
-MRS_DEV void contact_solve(const MrsParams &P, double pz, const M3 &R, V3 &v, V3 &w)
-{
-    const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
-    const double i0 = 1.0 / P.inertia[0], i1 = 1.0 / P.inertia[1], i2 = 1.0 / P.inertia[2], im = 1.0 / P.mass;
-    Sym3 Iw;
-    Iw.xx = R.m00 * R.m00 * i0 + R.m01 * R.m01 * i1 + R.m02 * R.m02 * i2;
-    Iw.xy = R.m00 * R.m10 * i0 + R.m01 * R.m11 * i1 + R.m02 * R.m12 * i2;
-    Iw.xz = R.m00 * R.m20 * i0 + R.m01 * R.m21 * i1 + R.m02 * R.m22 * i2;
-    Iw.yy = R.m10 * R.m10 * i0 + R.m11 * R.m11 * i1 + R.m12 * R.m12 * i2;
-    Iw.yz = R.m10 * R.m20 * i0 + R.m11 * R.m21 * i1 + R.m12 * R.m22 * i2;
-    Iw.zz = R.m20 * R.m20 * i0 + R.m21 * R.m21 * i1 + R.m22 * R.m22 * i2;
-    // body-frame rim points (+-c, +-c, +-hl): r = sx c Rcol0 + sy c Rcol1 + sz hl Rcol2
-    const V3 cx = v3(c * R.m00, c * R.m10, c * R.m20), cy = v3(c * R.m01, c * R.m11, c * R.m21), cz = v3(hl * R.m02, hl * R.m12, hl * R.m22);
-    unsigned active = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double rz = ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z);
-        const bool lower_cap = (R.m22 >= 0) ? ((k & 4) != 0) : ((k & 4) == 0); // only the cap facing the ground
-        if (lower_cap && pz + rz - P.ground_z <= P.contact_threshold) active |= 1u << k;
-    }
-    if (!active) return;
-    float ln[8], lx[8], ly[8];
-    // effective masses and the normal rhs depend only on the pre-solve state: computed once per point
-    // (3 float64 divisions each) instead of once per point per sweep
-    double Kn[8], Kx[8], Ky[8], rhs[8];
-    const double rdt = 1.0 / P.dt;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        ln[k] = 0.f; lx[k] = 0.f; ly[k] = 0.f;
-        Kn[k] = 0.; Kx[k] = 0.; Ky[k] = 0.; rhs[k] = 0.;
-        if (!(active & (1u << k))) continue;
-        const V3 r = v3(((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x),
-                        ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y),
-                        ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z));
-        const V3 un = v3(r.y, -r.x, 0.), ux = v3(0., r.z, -r.y), uy = v3(-r.z, 0., r.x);
-        const V3 In = symmul(Iw, un), Ix = symmul(Iw, ux), Iy = symmul(Iw, uy);
-        Kn[k] = 1.0 / (im + (un.x * In.x + un.y * In.y));
-        Kx[k] = 1.0 / (im + (ux.y * Ix.y + ux.z * Ix.z));
-        Ky[k] = 1.0 / (im + (uy.x * Iy.x + uy.z * Iy.z));
-        const double dist = pz + r.z - P.ground_z;
-        const double vrel0 = v.z + (w.x * r.y - w.y * r.x);
-        double poserr = 0., velerr = -vrel0;
-        if (dist > 0) velerr -= dist * rdt; else poserr = -dist * P.erp * rdt;
-        rhs[k] = poserr + velerr;
-    }
-    const V3 v0 = v, w0 = w;
-    for (int it = 0; it < P.solver_iters; ++it) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (!(active & (1u << k))) continue;
-            const V3 r = v3(((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + ((k & 4) ? -cz.x : cz.x),
-                            ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + ((k & 4) ? -cz.y : cz.y),
-                            ((k & 1) ? -cx.z : cx.z) + ((k & 2) ? -cy.z : cy.z) + ((k & 4) ? -cz.z : cz.z));
-            { // normal (+z): u = r x z = (r.y, -r.x, 0)
-                const V3 u = v3(r.y, -r.x, 0.);
-                const V3 Iu = symmul(Iw, u);
-                const double K = Kn[k];
-                const double dvn = (v.z - v0.z) + ((w.x - w0.x) * r.y - (w.y - w0.y) * r.x);
-                double nl = (double)ln[k] + K * (rhs[k] - dvn);
-                nl = nl < 0 ? 0 : nl;
-                const double dl = nl - (double)ln[k];
-                ln[k] = (float)nl;
-                v.z += dl * im;
-                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
-            }
-            const double lim = P.friction * (double)ln[k];
-            { // friction x: u = r x x = (0, r.z, -r.y)
-                const V3 u = v3(0., r.z, -r.y);
-                const V3 Iu = symmul(Iw, u);
-                const double K = Kx[k];
-                const double vt = v.x + (w.y * r.z - w.z * r.y);
-                const double nl = clampd((double)lx[k] - K * vt, -lim, lim);
-                const double dl = nl - (double)lx[k];
-                lx[k] = (float)nl;
-                v.x += dl * im;
-                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
-            }
-            { // friction y: u = r x y = (-r.z, 0, r.x)
-                const V3 u = v3(-r.z, 0., r.x);
-                const V3 Iu = symmul(Iw, u);
-                const double K = Ky[k];
-                const double vt = v.y + (w.z * r.x - w.x * r.z);
-                const double nl = clampd((double)ly[k] - K * vt, -lim, lim);
-                const double dl = nl - (double)ly[k];
-                ly[k] = (float)nl;
-                v.y += dl * im;
-                w.x += Iu.x * dl; w.y += Iu.y * dl; w.z += Iu.z * dl;
-            }
-        }
-    }
 }
 
 // BulletSim.step_sim -> stepSimulation (BulletSim.py:46-47).  [BULLET-KNOWLEDGE] btMultiBody ABA for a
@@ -681,14 +594,12 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
     v[0] = clampd(v[0] + vdot.x * dt, -mv, mv); v[1] = clampd(v[1] + vdot.y * dt, -mv, mv); v[2] = clampd(v[2] + vdot.z * dt, -mv, mv);
 }
 
-// The same solver with float32 internals (default in k_contact): geometry, gaps and the rhs are formed
-// in float64, the sweeps run on float32 velocity CHANGES (dv, dw) added back to the float64 state at
-// the end.  Impulses are ~m g dt = 2.6e-3 N s, so float32 carries them to ~1e-10; the contact model is
-// the build's own (no Bullet parity to lose) and its stated tolerance against the float64 oracle is
-// 1e-3.  Half the issue cycles and ~100 VGPRs less than the float64 form.
-#ifndef MRS_CONTACT_F32
-#define MRS_CONTACT_F32 1
-#endif
+// Ground contact, the build's own model (DESIGN.md "Row G"; the algorithm of oracle/mrs_oracle.c:contact_solve):
+// the 4 body-fixed rim points (azimuths 45 + 90 k degrees) of the cap of the collision cylinder that faces the ground
+// against z = ground_z, Bullet-style velocity-level rhs, sequential impulses with a friction pyramid along world x/y.
+// Geometry, gaps and the rhs are formed in float64; the sweeps run in float32 on velocity CHANGES (dv, dw), which the
+// caller adds to the float64 state.  Impulses are ~m g dt = 2.6e-3 N s, so float32 carries them to ~1e-10; the stated
+// tolerance against the float64 oracle is 1e-4 per step, 1e-3 over a touchdown.
 #ifndef MRS_CONTACT_TOL
 #define MRS_CONTACT_TOL 1e-7f
 #endif
@@ -811,15 +722,10 @@ MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3
 {
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
     V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
-#if MRS_CONTACT_F32
     F3 dv, dw;
     contact_solve_f32(P, K, p[2], R, vv, ww, dv, dw);
     v[0] += (double)dv.x; v[1] += (double)dv.y; v[2] += (double)dv.z;
     w[0] += (double)dw.x; w[1] += (double)dw.y; w[2] += (double)dw.z;
-#else
-    contact_solve(P, p[2], R, vv, ww);
-    v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; w[0] = ww.x; w[1] = ww.y; w[2] = ww.z;
-#endif
 }
 
 // The fused kernel's form: only the float32 velocity changes come back (see contact_solve_f32).

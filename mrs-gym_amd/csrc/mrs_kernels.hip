@@ -35,6 +35,10 @@ struct StepArgs {
     Recips rc;
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
+    // N = 64 fused step: downwash carried from the previous step (library workspace, see adjacency_phase)
+    DownwashConst dc;   // host-computed once per call
+    float4 *dw_pos;     // [T] float32 position the carried force belongs to (w unused)
+    double *dw_f;       // [T] the force: sum of the pair terms of Quadcopter.py:99-115
 };
 
 // Velocity planes: float64 like Bullet's state, or (MRS_VEL_F32) float32 -- what every consumer of the state reads
@@ -152,8 +156,9 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
-template <int BLOCK, int NFIX = 0>
-__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, uint64_t *row, float4 mine)
+template <int BLOCK, int NFIX = 0, bool DW = false>
+__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, uint64_t *row, float4 mine,
+                                                float4 *dw_pos = nullptr, double *dw_f = nullptr)
 {
     const bool n64 = (BLOCK == 256) && (NFIX == 64 || A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
@@ -165,6 +170,12 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
         // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
         // it is relative bit 64-k; k = 32 is tested by both ends.  One 64-bit rotate by the lane index at
         // the end turns relative into absolute columns.
+        //
+        // DW: the same loop also evaluates the NEXT step's downwash (Quadcopter.py:99-115 reads the pre-step
+        // positions of step t+1, which are the post-step positions this loop is looking at): neighbour read, the
+        // three differences and dxy^2 are shared with the range test, and the next step starts without its own
+        // pair loop.  The force is stored with the float32 position it belongs to; a step whose positions differ
+        // from that (set_state, reset, a restored checkpoint, a caller writing the buffers) recomputes it.
         if (live) {
             const int lane = tid & 63;
             const float4 *nb = lds_tile + el * 128 + lane;
@@ -173,27 +184,83 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
             // collect in `hr` at bit k too and are mirrored into place (relative bit 64-k) by one v_bfrev at
             // the end: one select and two ORs per pair, no per-pair shifts
             uint32_t lo = 0, hr = 0, top = 0;
+            const bool want_dw = DW && dw_pos != nullptr;
+            float acc32 = 0.f, pend = 0.f;
+            double dacc = 0.;
+            auto pairs = [&](auto with_dw) {
+                DownwashRegs dr = {0.f, 0.f, 0.f};
+                if (with_dw) dr = downwash_regs(A.dc);
 #pragma unroll
-            for (int k = 1; k <= 32; ++k) {
-                const float4 pj = nb[k];
-                const float dx = f32sub(mine.x, pj.x), dy = f32sub(mine.y, pj.y), dz = f32sub(mine.z, pj.z);
-                const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
-                const bool close = A.comm_inf || (d2 <= A.d2_thresh);
-                if (k < 32) {
-                    const uint32_t bit = close ? (1u << k) : 0u;
-                    lo |= bit;
-                    hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
-                } else {
-                    top = close ? 1u : 0u; // relative bit 32: tested by both ends
+                for (int k = 1; k <= 32; ++k) {
+                    const float4 pj = nb[k];
+                    const float rx = f32sub(pj.x, mine.x), ry = f32sub(pj.y, mine.y), rz = f32sub(pj.z, mine.z);
+                    const float d2xy = f32fma(ry, ry, f32mul(rx, rx));
+                    const float d2 = f32fma(rz, rz, d2xy);
+                    const bool close = A.comm_inf || (d2 <= A.d2_thresh);
+                    if (k < 32) {
+                        const uint32_t bit = close ? (1u << k) : 0u;
+                        lo |= bit;
+                        hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
+                    } else {
+                        top = close ? 1u : 0u; // relative bit 32: tested by both ends
+                    }
+                    if (with_dw) { // same sequence of operations as downwash_ring64: bit-identical force
+                        if (k < 32) {
+                            const float F = downwash_mag2(d2xy, fabsf(rz), dr.dw2, dr.dw3, dr.lg);
+                            const bool above = rz > 0.f;
+                            const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
+                            const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
+                            // the term handed over by lane i-k is added one pair LATE (its cross-lane round trip then overlaps
+                            // the next pair's arithmetic); the sums are anchored so that they are formed here and not sunk to
+                            // the end of the loop, which would keep all 31 handed-over terms alive (spills)
+                            acc32 = f32add(f32add(acc32, pend), f_self);
+                            asm volatile("" : "+v"(acc32));
+                            pend = f_in;
+                            if ((k & 7) == 0) { dacc += (double)acc32; acc32 = 0.f; }
+                        } else {
+                            acc32 = f32add(f32add(acc32, pend), rz > 0.f ? downwash_mag2(d2xy, rz, dr.dw2, dr.dw3, dr.lg) : 0.f);
+                            dacc += (double)acc32;
+                        }
+                    }
                 }
-            }
+            };
+            if (DW && want_dw) pairs(std::true_type{}); else pairs(std::false_type{});
             const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
             const uint64_t rel = ((uint64_t)hi << 32) | lo;
-            row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+            if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+            if (DW && want_dw) { *dw_pos = make_float4(mine.x, mine.y, mine.z, 0.f); *dw_f = dacc; }
         }
     } else if (live) {
         adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], row);
     }
+}
+
+// The downwash of an N = 64 env from its LDS tile (doubled layout), evaluated once per unordered pair: see k_step.
+// The fused adjacency loop above carries the identical sequence of operations.
+__device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, float my, float mz, int lane4, const DownwashConst &dc)
+{
+    const DownwashRegs dr = downwash_regs(dc);
+    float acc32 = 0.f, pend = 0.f;
+    double dacc = 0.;
+#pragma unroll
+    for (int k = 1; k < 32; ++k) {
+        const float4 pj = nb[k];
+        const float rx = f32sub(pj.x, mx), ry = f32sub(pj.y, my), rz = f32sub(pj.z, mz);
+        const float F = downwash_mag2(f32fma(ry, ry, f32mul(rx, rx)), fabsf(rz), dr.dw2, dr.dw3, dr.lg); // 0 when dz == 0
+        const bool above = rz > 0.f;
+        const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
+        // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
+        const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
+        acc32 = f32add(f32add(acc32, pend), f_self); // the handed-over term joins one pair late: see adjacency_phase
+        asm volatile("" : "+v"(acc32));
+        pend = f_in;
+        if ((k & 7) == 0) { dacc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
+    }
+    const float4 pj = nb[32];
+    const float rx = f32sub(pj.x, mx), ry = f32sub(pj.y, my), rz = f32sub(pj.z, mz);
+    acc32 = f32add(f32add(acc32, pend), rz > 0.f ? downwash_mag2(f32fma(ry, ry, f32mul(rx, rx)), rz, dr.dw2, dr.dw3, dr.lg) : 0.f);
+    dacc += (double)acc32;
+    return dacc;
 }
 
 // ------------------------------------------------------------------------------------ step kernel
@@ -218,6 +285,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 #endif
 #ifndef MRS_NFIX64
 #define MRS_NFIX64 0
+#endif
+#ifndef MRS_DW_CARRY
+#define MRS_DW_CARRY 0 // measured: 31.6 vs 30.3 us per step (the start of the kernel has idle issue slots while the state loads are in flight, its tail has none)
 #endif
 #ifndef MRS_EARLY_TAIL
 #define MRS_EARLY_TAIL 0
@@ -257,7 +327,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
 template <int ACT, int BLOCK, bool FUSED, int NFIX = 0>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
 {
-    const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / NFIX : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
+    const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / (NFIX ? NFIX : 1) : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
@@ -283,7 +353,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const size_t T = (size_t)A.T;
     const size_t a = live ? (size_t)e * AN + i : 0;
     const unsigned la = live ? (unsigned)tid : 0u;                                        // a == wg_base + la
-    const WgBuffers wb = wg_buffers(A, (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN);
+    const size_t wb_base = (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN;
+    const WgBuffers wb = wg_buffers(A, wb_base);
     constexpr int ADIM = (ACT == MRS_ACT_SET_SPEEDS || ACT == MRS_ACT_SET_CONTROL) ? 4 : 3;
 
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
@@ -311,8 +382,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #if MRS_DEFER_LOADS
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    // N = 64, fused: the downwash of this step was evaluated by the previous step's adjacency loop (adjacency_phase)
+    // and is valid iff it was computed from exactly these float32 positions; otherwise the env runs its own pair loop.
+    bool have_dw = false;
+    double downwash_acc = 0;
+#if MRS_DW_CARRY && !MRS_EXACT_F32
+    const bool carry = FUSED && n64 && A.dw_pos != nullptr && ACT != MRS_ACT_NONE;
+    if (carry) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) { c = (A.dw_pos + wb_base)[la]; downwash_acc = (A.dw_f + wb_base)[la]; }
+        const bool stale = live && !(c.x == (float)p[0] && c.y == (float)p[1] && c.z == (float)p[2]);
+        have_dw = __builtin_amdgcn_ballot_w64(stale) == 0; // the wave is the env
+        if (!have_dw) downwash_acc = 0;
+    }
+#else
+    const bool carry = false;
+#endif
     if (n64) {
-        lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+        if (!have_dw) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     } else {
         lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     }
@@ -358,7 +445,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (FUSED) SETPRIO(MRS_P_DW1, MRS_PA_DW, MRS_PB_DW);
     int my_slot = -1;
     bool parked = false;
-    double downwash_acc = 0;
 #if !MRS_EXACT_F32
     // ---- downwash, envs that span several waves (64 < N <= 256, fused kernel): the pair term is symmetric
     // (see the N = 64 loop below), so lane i evaluates the pairs (i, i+k) at ring distance k = 1..(N-1)/2 once and
@@ -371,7 +457,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (ring) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
         const float4 *tile_env = lds_tile + el * AN;
-        const DownwashConst dc = downwash_const(A.P);
+        const DownwashConst &dc = A.dc;
         const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
         const int half = (AN - 1) / 2;
         for (int k0 = 1; k0 <= half; k0 += RING_R) {
@@ -417,7 +503,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // kernel at 4 resident waves per SIMD.
         if (ACT != MRS_ACT_NONE && !ring) {
             const float4 *tile_env = lds_tile + el * AN;
-            const DownwashConst dc = downwash_const(A.P);
+            const DownwashConst &dc = A.dc;
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
 #if !MRS_EXACT_F32
             if (BLOCK == 256 && AN == 64) {
@@ -427,27 +513,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // i+k (one ds_bpermute) if the other is below; k = 32 pairs lanes with their antipode, each
                 // side evaluating its own.  32 evaluations per lane instead of 64.  (`doit` is uniform per
                 // env, so the whole wave is here.)
-                const int lane = tid & 63;
-                const float4 *nb = lds_tile + el * 128 + lane; // nb[k] = neighbour (lane + k) mod 64, no wrap
-                const int lane4 = lane << 2;                     // ds_bpermute byte address of this lane
-                float acc32 = 0.f;
-#pragma unroll
-                for (int k = 1; k < 32; ++k) {
-                    const float4 pj = nb[k];
-                    const float dz = pj.z - mz;
-                    const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc); // 0 when dz == 0
-                    const bool above = dz > 0.f;
-                    const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
-                    // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
-                    const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
-                    acc32 += f_self + f_in;
-                    if ((k & 7) == 0) { downwash_acc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
-                    if (FUSED && k == 16 && MRS_P_DW2 != MRS_P_DW1) __builtin_amdgcn_s_setprio(MRS_P_DW2);
+                if (!have_dw) {
+                    const int lane = tid & 63;
+                    // nb[k] = neighbour (lane + k) mod 64, no wrap; lane << 2 = ds_bpermute byte address of this lane
+                    downwash_acc = downwash_ring64(lds_tile + el * 128 + lane, mx, my, mz, lane << 2, A.dc);
                 }
-                const float4 pj = nb[32];
-                const float dz = pj.z - mz;
-                acc32 += dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f;
-                downwash_acc += (double)acc32;
             } else
 #endif
             {
@@ -655,7 +725,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #pragma unroll
                 for (int k = 0; k + 1 < NW; ++k) start = (seg == k + 1) ? wend[k] : start;
                 const int b = clist[seg * 64 + (sl - start)];
-#if MRS_CONTACT_F32
                 F3 dv, dw;
                 {
                     const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
@@ -666,15 +735,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // the float64 velocities are read again from the stash: nothing float64 is live across the sweeps
                 sp[7 * BLOCK + b] += (double)dv.x; sp[8 * BLOCK + b] += (double)dv.y; sp[9 * BLOCK + b] += (double)dv.z;
                 sp[10 * BLOCK + b] += (double)dw.x; sp[11 * BLOCK + b] += (double)dw.y; sp[12 * BLOCK + b] += (double)dw.z;
-#else
-                const double pp[3] = {0., 0., sp[2 * BLOCK + b]};
-                const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
-                double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
-                double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
-                contact_stage(A.P, A.rc, pp, qq, vv, ww);
-                sp[7 * BLOCK + b] = vv[0]; sp[8 * BLOCK + b] = vv[1]; sp[9 * BLOCK + b] = vv[2];
-                sp[10 * BLOCK + b] = ww[0]; sp[11 * BLOCK + b] = ww[1]; sp[12 * BLOCK + b] = ww[2];
-#endif
             }
             SETPRIO(0, MRS_PA_TAIL, MRS_PB_TAIL);
             TL(5); // own share of the contact solve
@@ -704,7 +764,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
 #endif
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
-        if (A.do_adj) adjacency_phase<BLOCK, NFIX>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)AW, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        if (A.do_adj || carry)
+            adjacency_phase<BLOCK, NFIX, (MRS_DW_CARRY != 0 && !MRS_EXACT_F32)>(A, lds_tile, tid, el, i, live, A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
+                                                              make_float4((float)p[0], (float)p[1], (float)p[2], 0.f),
+                                                              carry ? A.dw_pos + wb_base + la : nullptr, carry ? A.dw_f + wb_base + la : nullptr);
         TL(8); // observation + adjacency
         return;
     }
@@ -885,6 +948,11 @@ struct SpawnArgs {
     float min_dist;
     float ori_lo[3], ori_hi[3];
     size_t T;
+    // user START_POS distributions (MRS.py:127-154 with self.START_POS a torch distribution): the caller draws the
+    // samples, (E, cand_rounds, N, 3) float32 -- round r holds what every agent would get if it were re-sampled in
+    // round r -- and the greedy rejection runs here.  resume: start from the positions already in the state buffers.
+    const float *cand;
+    int cand_rounds, resume;
 };
 
 // MRS.generate_start_pos (MRS.py:127-154) for the default spawn distribution (MRS.py:69-78):
@@ -911,10 +979,20 @@ __global__ void k_spawn(const SpawnArgs S)
         if (mag > 1.f) { x /= mag; y /= mag; }
         sp[i] = make_float4(x, y, 1.f + 2.f * u3, 0.f);
     };
-    if (live) { sample(tid); flag[tid] = 0; }
+    int cand_next = 0; // next unused round of candidates (uniform over the workgroup)
+    if (S.cand) {
+        if (live) {
+            if (S.resume) sp[tid] = make_float4((float)S.b.pos[(size_t)e * S.N + tid], (float)S.b.pos[S.T + (size_t)e * S.N + tid],
+                                                (float)S.b.pos[2 * S.T + (size_t)e * S.N + tid], 0.f);
+            else { const float *c = S.cand + (((size_t)e * S.cand_rounds) * S.N + tid) * 3; sp[tid] = make_float4(c[0], c[1], c[2], 0.f); }
+            flag[tid] = 0;
+        }
+        cand_next = S.resume ? 0 : 1;
+    } else if (live) { sample(tid); flag[tid] = 0; }
     draws += 3;
     __syncthreads();
     int round = 0;
+    bool need_more = false;
     for (;; ++round) {
         if (live) { // codist < 2*AGENT_RADIUS (MRS.py:135-138)
             int c = 0;
@@ -949,15 +1027,24 @@ __global__ void k_spawn(const SpawnArgs S)
         }
         __syncthreads();
         if (s_total == 0 || round >= S.max_rounds) break;
-        if (live && flag[tid]) { sample(tid); flag[tid] = 0; } // MRS.py:146-151
+        if (S.cand) {
+            if (cand_next >= S.cand_rounds) { need_more = true; break; } // out of samples: the caller draws more and resumes
+            if (live && flag[tid]) {
+                const float *c = S.cand + (((size_t)e * S.cand_rounds + cand_next) * S.N + tid) * 3;
+                sp[tid] = make_float4(c[0], c[1], c[2], 0.f);
+                flag[tid] = 0;
+            }
+            cand_next++;
+        } else if (live && flag[tid]) { sample(tid); flag[tid] = 0; } // MRS.py:146-151
         draws += 3;
         __syncthreads();
     }
-    if (tid == 0 && s_total != 0 && S.b.status) atomicOr(&S.b.status[e], MRS_STATUS_SPAWN_FAIL);
+    if (tid == 0 && s_total != 0 && S.b.status) atomicOr(&S.b.status[e], need_more ? MRS_STATUS_SPAWN_MORE : MRS_STATUS_SPAWN_FAIL);
     if (live) {
         const size_t a = (size_t)e * S.N + tid, T = S.T;
         const float4 me = sp[tid];
         S.b.pos[a] = (double)me.x; S.b.pos[T + a] = (double)me.y; S.b.pos[2 * T + a] = (double)me.z;
+        if (S.cand) return; // positions only: orientation / velocities follow through mrs_set_state (MRS.reset)
         // MRS.generate_start_ori (MRS.py:157-161): randrange(lo, hi) per axis
         float eul[3];
         for (int k = 0; k < 3; ++k) {
@@ -1031,6 +1118,8 @@ struct MrsHandle {
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
     bool fused;         // one-launch step (256-thread workgroups; MRS_STEP_SPLIT=1 keeps the three-launch form)
     unsigned step_parity;
+    float4 *dw_pos;     // device workspace, N = 64 fused step: downwash carried between steps (see adjacency_phase):
+    double *dw_f;       //   the float32 position it was evaluated at, and the force
 };
 
 static thread_local char g_err[256] = "";
@@ -1129,6 +1218,12 @@ extern "C" int mrs_set_params(MrsHandle *h, const MrsParams *params)
     double d[7];
     mrs_params_derived(params, d);
     h->hclip = d[6];
+    if (h->dw_pos) { // a carried downwash force belongs to the old coefficients: forget it
+        DeviceGuard dg(h->device);
+        hipError_t e = hipMemset(h->dw_pos, 0xFF, (size_t)h->E * h->N * sizeof(float4));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return hipfail(e, "mrs_set_params");
+    }
     return 0;
 }
 
@@ -1150,6 +1245,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     h->W = (n_agents + 63) / 64;
     const char *split = getenv("MRS_STEP_SPLIT");
     h->fused = (h->block == 256) && !(split && split[0] == '1');
+    h->dw_pos = nullptr; h->dw_f = nullptr;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
@@ -1164,8 +1260,19 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
+    h->dw_pos = nullptr; h->dw_f = nullptr;
+    if (e == hipSuccess && h->fused && n_agents == 64 && MRS_DW_CARRY) {
+        const size_t T = (size_t)n_envs * n_agents;
+        e = hipMalloc((void **)&h->dw_pos, T * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->dw_f, T * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(h->dw_pos, 0xFF, T * sizeof(float4)); // NaN positions: nothing carried yet
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
     if (e != hipSuccess) {
         if (h->ws) (void)hipFree(h->ws);
+        if (h->cs) (void)hipFree(h->cs);
+        if (h->dw_pos) (void)hipFree(h->dw_pos);
+        if (h->dw_f) (void)hipFree(h->dw_f);
         (void)hipSetDevice(cur);
         delete h;
         return hipfail(e, "mrs_create workspace");
@@ -1178,14 +1285,12 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
-    if (h->ws) {
-        int cur = 0;
-        if (hipGetDevice(&cur) == hipSuccess) {
-            (void)hipSetDevice(h->device);
-            (void)hipFree(h->ws);
-            if (h->cs) (void)hipFree(h->cs);
-            (void)hipSetDevice(cur);
-        }
+    if (h->ws || h->cs || h->dw_pos || h->dw_f) {
+        DeviceGuard dg(h->device);
+        if (h->ws) (void)hipFree(h->ws);
+        if (h->cs) (void)hipFree(h->cs);
+        if (h->dw_pos) (void)hipFree(h->dw_pos);
+        if (h->dw_f) (void)hipFree(h->dw_f);
     }
     delete h;
 }
@@ -1205,6 +1310,13 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
 {
     memset(&A, 0, sizeof(A));
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
+    { // Quadcopter.py:103-110 constants of the pair term, float32 like the reference's arithmetic (see DownwashConst)
+        DownwashConst &c = A.dc;
+        c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
+        c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
+        c.lg_alpha = (float)std::log2((double)c.c_alpha);
+        A.dw_pos = h->dw_pos; A.dw_f = h->dw_f;
+    }
     A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
     A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf); A.rc.inv_dt = 1.0 / h->P.dt;
     const int D = mrs_obs_dim(obs_fields, n_obs);
@@ -1411,6 +1523,23 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn launch");
+}
+
+extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *candidates, int n_rounds, int resume, double agent_radius,
+                              const uint8_t *env_mask, void *stream)
+{
+    if (!h || !b || !candidates) return fail(MRS_E_ARG, "mrs_spawn_from: NULL argument");
+    if (n_rounds < 1) return fail(MRS_E_ARG, "mrs_spawn_from: n_rounds must be >= 1");
+    DeviceGuard dg(h->device);
+    SpawnArgs S;
+    memset(&S, 0, sizeof(S));
+    S.b = *b; S.mask = env_mask; S.E = h->E; S.N = h->N; S.max_rounds = 1 << 30; S.min_dist = (float)(2 * agent_radius);
+    S.T = (size_t)h->E * h->N; S.cand = candidates; S.cand_rounds = n_rounds; S.resume = resume;
+    const int block = ((h->N + 63) / 64) * 64;
+    const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
+    hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn_from launch");
 }
 
 // ---------------------------------------------------------------------------------------------------- sensors

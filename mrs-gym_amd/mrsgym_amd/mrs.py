@@ -233,34 +233,69 @@ class MRS(_EnvBase):
         N = pos.shape[-2]
         return pos.unsqueeze(-2).expand(*pos.shape[:-2], N, N, 3) - pos.unsqueeze(-3).expand(*pos.shape[:-2], N, N, 3)
 
-    def generate_start_pos(self):  # MRS.py:127-154, host path for tensors / user distributions
+    @staticmethod
+    def _draw(dist, k):
+        """k independent samples of `dist`, stacked on a new leading axis -- one batched call when the distribution
+        supports sample_shape (torch's own and util.CombinedDistribution do), k calls otherwise."""
+        one = dist.sample()
+        # torch sizes its CPU thread pool by the machine, not by the container's share of it: a ~1 M element normal_() on
+        # 128 threads of a 16-core share stalls for ~90 ms every few calls (measured); a handful of threads take 2 ms
+        nt = torch.get_num_threads()
+        if nt > 8:
+            torch.set_num_threads(4)
+        try:
+            try:
+                x = dist.sample((k,))
+                if tuple(x.shape) == (k,) + tuple(one.shape):
+                    return x
+            except Exception:
+                pass
+            return torch.stack([dist.sample() for _ in range(k)])
+        finally:
+            if nt > 8:
+                torch.set_num_threads(nt)
+
+    def _spawn_user(self, env_mask=None, rounds=4):
+        """MRS.generate_start_pos (MRS.py:127-154) for START_POS given as a distribution, for all (masked) envs at once:
+        the samples are drawn in bulk on the host (torch.distributions lives there) -- `rounds` re-sampling rounds per
+        env up front -- and the greedy rejection runs on the device (mrs_spawn_from).  Writes positions only."""
+        sp, E, N, sh = self.START_POS, self.N_ENVS, self.N_AGENTS, self.shard
+        per_agent = sp.sample().dim() == 1          # (3,) per-agent samples vs (N,3) joint samples (MRS.py:129-132)
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.bool).reshape(E)
+        sh.status.bitwise_and_(~(native.STATUS_SPAWN_MORE | native.STATUS_SPAWN_FAIL))
+        resume = False
+        for attempt in range(64):
+            idx = torch.arange(E) if mask is None else torch.nonzero(mask.cpu()).flatten()
+            if idx.numel() == 0:
+                return
+            n = int(idx.numel())
+            x = self._draw(sp, n * rounds * N).reshape(n, rounds, N, 3) if per_agent else self._draw(sp, n * rounds).reshape(n, rounds, N, 3)
+            cand = torch.zeros(E, rounds, N, 3, dtype=torch.float32) if n != E else None
+            if cand is None:
+                cand = x.to(torch.float32)
+            else:
+                cand[idx] = x.to(torch.float32)
+            sh.spawn_from(cand.to(self.device), agent_radius=self.AGENT_RADIUS, env_mask=mask, resume=resume)
+            more = (sh.status & native.STATUS_SPAWN_MORE) != 0      # one host sync per attempt
+            if not bool(more.any()):
+                return
+            sh.status.bitwise_and_(~native.STATUS_SPAWN_MORE)
+            mask, resume, rounds = more, True, min(64, rounds * 2)
+        raise RuntimeError("START_POS: no layout with all pairs >= 2*AGENT_RADIUS = %.2f m apart after many re-sampling "
+                           "rounds (the reference's generate_start_pos would still be looping, MRS.py:137-153)" % (2 * self.AGENT_RADIUS))
+
+    def generate_start_pos(self):  # MRS.py:127-154
+        """Start positions as a tensor: START_POS itself if it is one, else one batched draw + device-side rejection
+        (the state buffers are used as scratch: reset()/reset_envs() call _spawn_user directly instead)."""
         E, N = self.N_ENVS, self.N_AGENTS
         sp = self.START_POS
         if isinstance(sp, torch.Tensor):
             return sp if sp.dim() == 3 else sp.unsqueeze(0).expand(E, N, 3)
-        # user distribution: per-agent (3,) samples or joint (N,3) samples; greedy re-sampling of the most
-        # colliding agents until every pair is >= 2*AGENT_RADIUS apart (same rule as k_spawn, one env at a time)
-        per_agent = sp.sample().dim() == 1
-        draw = (lambda: torch.stack([sp.sample() for _ in range(N)])) if per_agent else sp.sample
-        min_d = 2 * self.AGENT_RADIUS
-        envs = []
-        for _ in range(E):
-            pts = draw().clone()
-            while True:
-                close = torch.cdist(pts, pts) < min_d
-                close.fill_diagonal_(False)
-                if not bool(close.any()):
-                    break
-                redo = []
-                while bool(close.any()):
-                    worst = int(close.sum(dim=1).argmax())     # most collisions, lowest index on ties
-                    redo.append(worst)
-                    close[worst, :] = False
-                    close[:, worst] = False
-                fresh = draw()
-                pts[redo] = fresh[redo]
-            envs.append(pts)
-        return torch.stack(envs, 0)
+        saved = self.shard.pos.clone()
+        self._spawn_user()
+        out = self.shard.view(self.shard.pos).to(torch.float32).clone()
+        self.shard.pos.copy_(saved)
+        return out
 
     def generate_start_ori(self):  # MRS.py:157-161
         so = torch.as_tensor(self.START_ORI)
@@ -306,8 +341,10 @@ class MRS(_EnvBase):
             spawned = self._default_spawn()
             if not spawned:
                 saved, self.START_POS = self.START_POS, self.default_spawn_dist()
-                pos = self.generate_start_pos()
+                self._spawn_user()
                 self.START_POS = saved
+        elif pos is None and not isinstance(self.START_POS, torch.Tensor):
+            self._spawn_user()                       # positions are on the device already: set_state keeps them (pos=None)
         elif pos is None:
             pos = self.generate_start_pos()
         if ori is None and not spawned:
@@ -347,8 +384,10 @@ class MRS(_EnvBase):
             spawned = self._default_spawn(env_mask=mask)
             if not spawned:
                 saved, self.START_POS = self.START_POS, self.default_spawn_dist()
-                pos = self.generate_start_pos()
+                self._spawn_user(env_mask=mask)      # samples are drawn for the selected envs only
                 self.START_POS = saved
+        elif pos is None and not isinstance(self.START_POS, torch.Tensor):
+            self._spawn_user(env_mask=mask)
         elif pos is None:
             pos = self.generate_start_pos()
         if ori is None and not spawned:

@@ -25,12 +25,12 @@ ACT_DIM = {0: 0, 1: 4, 2: 4, 3: 3, 4: 3, 5: 3, 6: 3}
 OBS = {"pos": 0, "vel": 1, "ori": 2, "euler": 2, "angvel": 3, "quat": 4}
 OBS_WIDTH = {0: 3, 1: 3, 2: 3, 3: 3, 4: 4}
 ORI_EULER, ORI_QUAT, ORI_MATRIX = 0, 1, 2
-STATUS_NAN_ACTION, STATUS_SPAWN_FAIL = 1, 2
+STATUS_NAN_ACTION, STATUS_SPAWN_FAIL, STATUS_SPAWN_MORE = 1, 2, 4
 EXPORTS = [
     "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
     "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
     "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn", "mrs_reynolds",
-    "mrs_raycast", "mrs_proximity", "mrs_flock_metrics",
+    "mrs_raycast", "mrs_proximity", "mrs_flock_metrics", "mrs_spawn_from",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.mrs_reynolds.argtypes = [vp, vp, C.c_int, vp, vp]
         L.mrs_raycast.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]
         L.mrs_proximity.argtypes = [vp, C.POINTER(MrsBuffers), C.c_double, vp, vp, vp, vp]
+        L.mrs_spawn_from.argtypes = [vp, C.POINTER(MrsBuffers), vp, C.c_int, C.c_int, C.c_double, vp, vp]
         L.mrs_flock_metrics.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
@@ -324,6 +325,17 @@ class SwarmShard:
         self.version += 1
         _check(self.L.mrs_spawn(self.h, C.byref(b), int(seed) & (2 ** 64 - 1), int(env_index_base), float(agent_radius),
                                 lo, hi, int(max_rounds), _ptr(mask), _stream(self.device)), "mrs_spawn")
+
+    def spawn_from(self, candidates, agent_radius=0.3, env_mask=None, resume=False):
+        """mrs_spawn_from: candidates (E, R, N, 3) float32 device tensor; positions only (see include/mrs_hip.h)."""
+        c = candidates.to(device=self.device, dtype=torch.float32).contiguous()
+        if c.dim() != 4 or c.shape[0] != self.E or c.shape[2] != self.N or c.shape[3] != 3:
+            raise ValueError("candidates must be (E=%d, rounds, N=%d, 3), got %s" % (self.E, self.N, tuple(c.shape)))
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
+        b = self._buffers()
+        self.version += 1
+        _check(self.L.mrs_spawn_from(self.h, C.byref(b), _ptr(c), int(c.shape[1]), int(bool(resume)), float(agent_radius), _ptr(mask),
+                                     _stream(self.device)), "mrs_spawn_from")
 
     def reynolds(self, x_prev, actions_out=None):
         """Reynolds expert (mrs_reynolds): x_prev (E,N,D>=6) float32 device tensor -> (E,N,3) target velocities."""

@@ -23,14 +23,18 @@ class CombinedDistribution(Distribution):
         super().__init__(validate_args=False)
         self.dist, self.mixer, self.dim = list(dist), mixer, dim
 
-    def _mix(self, parts):
-        return (torch.stack if self.mixer == 'stack' else torch.cat)(parts, dim=self.dim)
+    def _mix(self, parts, lead=0):
+        # `dim` counts the axes of ONE sample; with sample_shape in front it moves right by that many axes
+        dim = self.dim + lead if self.dim >= 0 else self.dim
+        return (torch.stack if self.mixer == 'stack' else torch.cat)(parts, dim=dim)
 
-    def sample(self, *a, **k):
-        return self._mix([d.sample(*a, **k) for d in self.dist])
+    def sample(self, sample_shape=torch.Size()):
+        sample_shape = torch.Size(sample_shape)
+        return self._mix([d.sample(sample_shape) for d in self.dist], len(sample_shape))
 
-    def rsample(self, *a, **k):
-        return self._mix([d.rsample(*a, **k) for d in self.dist])
+    def rsample(self, sample_shape=torch.Size()):
+        sample_shape = torch.Size(sample_shape)
+        return self._mix([d.rsample(sample_shape) for d in self.dist], len(sample_shape))
 
     def expand(self, *a, **k):
         for d in self.dist:

@@ -93,6 +93,40 @@ def test_user_spawn_distribution_and_start_ori():
         assert float(yaw) <= 1.0 + 1e-6
 
 
+def test_user_spawn_is_batched_on_the_device():
+    """START_POS as a distribution at E = 4096, N = 12: one bulk draw + mrs_spawn_from, no per-env host
+    loop -- under 50 ms per reset() after the first; reset_envs() re-draws the selected envs only and moves only those."""
+    import time
+    import mrsgym_amd
+    from torch.distributions import Normal, Uniform
+    from mrsgym_amd.util import CombinedDistribution
+    E, N = 4096, 12
+    dist_ = CombinedDistribution([Normal(torch.zeros(N, 2), 1.25), Uniform(2.0 * torch.ones(N, 1), 5.0 * torch.ones(N, 1))], mixer='cat', dim=1)
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, START_POS=dist_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    X = env.reset()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = X[:, 0, :, :3]
+    d = torch.cdist(p, p) + 10 * torch.eye(N, device=p.device)
+    assert float(d.min()) >= 0.6 - 1e-6 and float(p[..., 2].min()) >= 2 and float(p[..., 2].max()) <= 5
+    assert float(p[..., :2].std()) > 1.0                                   # the Normal(0, 1.25) cloud, not a degenerate layout
+    assert dt < 0.05, "reset() took %.1f ms" % (dt * 1e3)
+    before = env.shard.view(env.shard.pos).clone()
+    mask = torch.zeros(E, dtype=torch.bool); mask[::7] = True
+    env.reset_envs(mask)
+    after = env.shard.view(env.shard.pos)
+    assert torch.equal(after[~mask.cuda()], before[~mask.cuda()]) and not torch.equal(after[mask.cuda()], before[mask.cuda()])
+    d = torch.cdist(after.float(), after.float()) + 10 * torch.eye(N, device=p.device)
+    assert float(d.min()) >= 0.6 - 1e-6
+    # per-agent (3,) samples, and a layout that needs many rounds (12 agents of radius 0.3 in a tight cloud)
+    single = CombinedDistribution([Normal(torch.zeros(2), 0.8), Uniform(2.0 * torch.ones(1), 3.0 * torch.ones(1))], mixer='cat', dim=0)
+    env2 = mrsgym_amd.make('mrs-v0', N_ENVS=64, N_AGENTS=N, state_fn=state_fn, START_POS=single)
+    p2 = env2.get_Xk()[:, 0, :, :3]
+    assert float((torch.cdist(p2, p2) + 10 * torch.eye(N, device=p2.device)).min()) >= 0.6 - 1e-6
+
+
 def test_callbacks_and_quirks():
     import mrsgym_amd
     N = 5

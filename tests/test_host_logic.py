@@ -133,3 +133,24 @@ def test_rollout_log_writes_the_reference_trainer_dict(tmp_path):
     with pytest.raises(IndexError):
         for _ in range(20):
             log.set_state(As[0], Xs[0])
+
+
+def test_combined_distribution_batched_sampling():
+    """util.CombinedDistribution.sample(sample_shape): the mixing axis counts the axes of ONE sample (Util.py:86-99 has no
+    sample_shape); MRS._draw batches a distribution that supports it and falls back to k calls for one that does not."""
+    import torch
+    from torch.distributions import Normal, Uniform
+    from mrsgym_amd.util import CombinedDistribution
+    from mrsgym_amd.mrs import MRS
+    N = 5
+    joint = CombinedDistribution([Normal(torch.zeros(N, 2), 1.25), Uniform(2.0 * torch.ones(N, 1), 5.0 * torch.ones(N, 1))], mixer='cat', dim=1)
+    single = CombinedDistribution([Normal(torch.zeros(2), 1.25), Uniform(2.0 * torch.ones(1), 5.0 * torch.ones(1))], mixer='cat', dim=0)
+    assert joint.sample().shape == (N, 3) and joint.sample((7,)).shape == (7, N, 3) and single.sample((4, 2)).shape == (4, 2, 3)
+    x = MRS._draw(joint, 11)
+    assert x.shape == (11, N, 3) and float(x[..., 2].min()) >= 2 and float(x[..., 2].max()) <= 5
+
+    class OneAtATime:                       # e.g. the reference's own CombinedDistribution: sample() only
+        def sample(self, *a):
+            assert not a or a[0] == ()
+            return torch.randn(3)
+    assert MRS._draw(OneAtATime(), 6).shape == (6, 3)
