@@ -172,7 +172,12 @@ MRS_DEV double fast_atan2(double y, double x)
 // scipy Rotation.as_matrix of the normalised quaternion (Object.py:93-95)
 MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
 {
-    const double rn = rsqrt64(qx * qx + qy * qy + qz * qz + qw * qw);
+    // |q|^2 = 1 + e with |e| <= 4e-7 here (a unit quaternion truncated to float32, Object.py:92-93):
+    // 1/sqrt(1 + e) = 1 - e/2 + 3e^2/8 - 5e^3/16 (+35e^4/128 ~ 1e-26); a caller's non-unit quaternion takes the rsqrt
+    const double e = (qx * qx + qy * qy + qz * qz + qw * qw) - 1.0;
+    double rn;
+    if (__builtin_amdgcn_ballot_w64(fabs(e) > 1e-5) == 0) rn = __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, -0.3125, 0.375), -0.5), 1.0);
+    else rn = rsqrt64(e + 1.0);
     const double x = qx * rn, y = qy * rn, z = qz * rn, w = qw * rn;
     const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
     const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
@@ -187,7 +192,12 @@ MRS_DEV M3 quat_to_matrix_scipy(double qx, double qy, double qz, double qw)
 MRS_DEV M3 quat_to_matrix_bullet(double qx, double qy, double qz, double qw)
 {
     const double d = qx * qx + qy * qy + qz * qz + qw * qw;
-    const double s = 2.0 * rcp64(d);
+    // the state quaternion is re-normalised by every step: d = 1 + e with |e| ~ 1e-16, where 1/d = 1 - e + e^2 is exact
+    // to double rounding; anything else (a caller's own quaternion through set_state) takes the division
+    const double e = d - 1.0;
+    double s;
+    if (__builtin_amdgcn_ballot_w64(fabs(e) > 1e-8) == 0) s = 2.0 * __builtin_fma(e, e - 1.0, 1.0);
+    else s = 2.0 * rcp64(d);
     const double xs = qx * s, ys = qy * s, zs = qz * s;
     const double wx = qw * xs, wy = qw * ys, wz = qw * zs;
     const double xx = qx * xs, xy = qx * ys, xz = qx * zs;
@@ -575,7 +585,9 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
     const V3 wb = mulT(R, v3(w[0], w[1], w[2]));
     const V3 gb = mulT(R, v3(0., 0., -P.gravity * P.mass));
     const V3 fb = fb_ext + gb;
-    const double nv = norm(vb), nw = norm(wb);
+    // |v|, |w| only scale the quadratic damping term k |v| v (k = 0.04): float32 square roots (1e-7 relative on a
+    // term that is itself ~4 % of the velocity per second) instead of two float64 ones
+    const double nv = (double)__builtin_sqrtf((float)dot(vb, vb)), nw = (double)__builtin_sqrtf((float)dot(wb, wb));
     const V3 Iw = v3(P.inertia[0] * wb.x, P.inertia[1] * wb.y, P.inertia[2] * wb.z);
     const V3 gyro = P.use_gyro ? cross(wb, Iw) : v3(0., 0., 0.);
     const V3 cor = cross(wb, vb);
@@ -736,24 +748,49 @@ MRS_DEV void contact_stage_delta(const MrsParams &P, const Recips &K, double pz,
     contact_solve_f32(P, K, pz, R, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw);
 }
 
+MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[3], const double w[3]);
 MRS_DEV void integrate_pose(const MrsParams &P, double p[3], double q[4], const double v[3], const double w[3])
 {
-    const double dt = P.dt;
+    integrate_pose(P.dt, p, q, v, w);
+}
+MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[3], const double w[3])
+{
+    // btMultiBody::stepPositionsMultiDof for the floating base: p += dt v; q <- dorn * q with the exponential map
+    //   fAngle = |w|;  if (fAngle dt > pi/4) fAngle = pi / (4 dt);
+    //   axis = w * (fAngle < 0.001 ? dt/2 - dt^3 0.020833333333 fAngle^2 : sin(fAngle dt / 2) / fAngle);  dorn = (axis, cos(fAngle dt / 2))
+    // in terms of x = (half angle)^2 = dt^2 |w|^2 / 4, without the square root and the division:
+    //   sin(h) / fAngle = (dt/2) sinc(h) = (dt/2) S(x),  cos(h) = C(x),  and the angular-motion threshold is x <= (pi/8)^2
+    // (at the threshold both forms agree, so clamping x reproduces that branch; Bullet's small-angle Taylor branch is
+    // the first two terms of S, its remainder < 1e-25).  S, C: Taylor to x^7 / x^8, remainder < 1e-17 on x <= (pi/8)^2.
     p[0] += dt * v[0]; p[1] += dt * v[1]; p[2] += dt * v[2];
-    double fAngle = sqrt64(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    if (fAngle * dt > 0.25 * kPi) fAngle = 0.5 * (0.5 * kPi) / dt;
-    double sc;
-    if (fAngle < 0.001)
-        sc = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle;
-    else
-        sc = ksin(0.5 * fAngle * dt) * rcp64(fAngle);   // half-angle <= pi/8 after the threshold above: kernel range
-    const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc, dw = kcos(fAngle * dt * 0.5);
+    const double x = fmin(0.25 * (dt * dt) * (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 0.15421256876702122);
+    double S = fma_c(x, 1.0 / 1307674368000.0, -1.0 / 6227020800.0);
+    S = fma_c(S, x, 1.0 / 39916800.0);
+    S = fma_c(S, x, -1.0 / 362880.0);
+    S = fma_c(S, x, 1.0 / 5040.0);
+    S = fma_c(S, x, -1.0 / 120.0);
+    S = fma_c(S, x, 1.0 / 6.0);
+    S = __builtin_fma(-S, x, 1.0);
+    double C = fma_c(x, -1.0 / 1307674368000.0 / 16.0 * 1.0, 1.0 / 87178291200.0);
+    C = fma_c(C, x, -1.0 / 479001600.0);
+    C = fma_c(C, x, 1.0 / 3628800.0);
+    C = fma_c(C, x, -1.0 / 40320.0);
+    C = fma_c(C, x, 1.0 / 720.0);
+    C = fma_c(C, x, -1.0 / 24.0);
+    C = fma_c(C, x, 0.5);
+    const double dw = __builtin_fma(-C, x, 1.0);
+    const double sc = (0.5 * dt) * S;
+    const double ax = w[0] * sc, ay = w[1] * sc, az = w[2] * sc;
     const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
     const double nx = dw * qx + ax * qw + ay * qz - az * qy;
     const double ny = dw * qy + ay * qw + az * qx - ax * qz;
     const double nz = dw * qz + az * qw + ax * qy - ay * qx;
     const double nw2 = dw * qw - ax * qx - ay * qy - az * qz;
-    const double rnn = rsqrt64(nx * nx + ny * ny + nz * nz + nw2 * nw2);
+    // |dorn| = 1 to rounding unless the threshold clamped x (|w| dt > pi/4): 1/sqrt(1 + e) = 1 - e/2 + 3e^2/8 is exact then
+    const double e = (nx * nx + ny * ny + nz * nz + nw2 * nw2) - 1.0;
+    double rnn;
+    if (__builtin_amdgcn_ballot_w64(fabs(e) > 1e-8) == 0) rnn = __builtin_fma(e, __builtin_fma(e, 0.375, -0.5), 1.0);
+    else rnn = rsqrt64(e + 1.0);
     q[0] = nx * rnn; q[1] = ny * rnn; q[2] = nz * rnn; q[3] = nw2 * rnn;
 }
 

@@ -29,6 +29,7 @@ struct StepArgs {
     int E, N, T, epb;
     int n_obs, D;
     int obs_fields[MRS_OBS_MAX_FIELDS];
+    unsigned obs_code; // the same field list, 4 bits per field (one scalar instead of an array in the argument segment)
     int do_adj, comm_inf, W;
     float d2_thresh;
     double hclip;
@@ -103,15 +104,15 @@ __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size
 }
 
 // newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
-__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
+__device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
 {
     bool want_euler = false;
-    for (int f = 0; f < A.n_obs; ++f) want_euler |= (A.obs_fields[f] == MRS_OBS_EULER);
+    for (int f = 0; f < n_obs; ++f) want_euler |= (((code >> (4 * f)) & 15u) == MRS_OBS_EULER);
     Observed ob;
     if (want_euler) observe<true, false>(p, q, v, w, ob); else observe<false, false>(p, q, v, w, ob);
     int off = 0;
-    for (int f = 0; f < A.n_obs; ++f) {
-        switch (A.obs_fields[f]) {
+    for (int f = 0; f < n_obs; ++f) {
+        switch ((code >> (4 * f)) & 15u) {
         case MRS_OBS_POS: o[off] = ob.px; o[off + 1] = ob.py; o[off + 2] = ob.pz; off += 3; break;
         case MRS_OBS_VEL: o[off] = ob.vx; o[off + 1] = ob.vy; o[off + 2] = ob.vz; off += 3; break;
         case MRS_OBS_EULER: o[off] = ob.roll; o[off + 1] = ob.pitch; o[off + 2] = ob.yaw; off += 3; break;
@@ -120,6 +121,10 @@ __device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const dou
         default: break;
         }
     }
+}
+__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
+{
+    write_obs(A.obs_code, A.n_obs, o, p, q, v, w);
 }
 
 // bit-packed adjacency row of agent i from the env's LDS position tile (MRS.calc_A, MRS.py:117-124):
@@ -157,10 +162,10 @@ __device__ __forceinline__ void wave_lds_sync()
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 template <int BLOCK, int NFIX = 0, bool DW = false>
-__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_tile, int tid, int el, int i, bool live, uint64_t *row, float4 mine,
-                                                float4 *dw_pos = nullptr, double *dw_f = nullptr)
+__device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
+                                                uint64_t *row, float4 mine, float4 *dw_pos = nullptr, double *dw_f = nullptr)
 {
-    const bool n64 = (BLOCK == 256) && (NFIX == 64 || A.N == 64);
+    const bool n64 = (BLOCK <= 256) && (NFIX == 64 || A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
     else lds_tile[tid] = mine;
     if (n64) wave_lds_sync(); else __syncthreads();
@@ -187,6 +192,12 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
             const bool want_dw = DW && dw_pos != nullptr;
             float acc32 = 0.f, pend = 0.f;
             double dacc = 0.;
+            // The range threshold lives in a VECTOR register for the loop (comm_range = inf arrives as thr = +inf from
+            // the host).  As a kernel argument it is re-read from the argument segment inside every pair once scalar
+            // registers are short -- s_load + s_waitcnt lgkmcnt(0), which also drains the pair's LDS read and every
+            // cross-lane transfer in flight: the loop then runs one pair per memory round trip.
+            float thr = thr_s;
+            asm volatile("" : "+v"(thr));
             auto pairs = [&](auto with_dw) {
                 DownwashRegs dr = {0.f, 0.f, 0.f};
                 if (with_dw) dr = downwash_regs(A.dc);
@@ -196,7 +207,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
                     const float rx = f32sub(pj.x, mine.x), ry = f32sub(pj.y, mine.y), rz = f32sub(pj.z, mine.z);
                     const float d2xy = f32fma(ry, ry, f32mul(rx, rx));
                     const float d2 = f32fma(rz, rz, d2xy);
-                    const bool close = A.comm_inf || (d2 <= A.d2_thresh);
+                    const bool close = d2 <= thr;
                     if (k < 32) {
                         const uint32_t bit = close ? (1u << k) : 0u;
                         lo |= bit;
@@ -224,9 +235,10 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float4 *lds_t
                     }
                 }
             };
-            if (DW && want_dw) pairs(std::true_type{}); else pairs(std::false_type{});
+            // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
+            if (DW && want_dw) pairs(std::true_type{}); else if (!comm_inf) pairs(std::false_type{});
             const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
-            const uint64_t rel = ((uint64_t)hi << 32) | lo;
+            const uint64_t rel = comm_inf ? ~1ull : (((uint64_t)hi << 32) | lo);
             if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
             if (DW && want_dw) { *dw_pos = make_float4(mine.x, mine.y, mine.z, 0.f); *dw_f = dacc; }
         }
@@ -252,7 +264,7 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
         // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
         const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
         acc32 = f32add(f32add(acc32, pend), f_self); // the handed-over term joins one pair late: see adjacency_phase
-        asm volatile("" : "+v"(acc32));
+        asm volatile("" : "+v"(acc32));              // (without the anchor two ACTION_TYPEs spill; measured equal otherwise)
         pend = f_in;
         if ((k & 7) == 0) { dacc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
     }
@@ -325,7 +337,7 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
 // k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
 // NFIX = 64: the instantiation for N_AGENTS = 64 (one env per wave; the generic-N branches fold away), 0: any N.
 template <int ACT, int BLOCK, bool FUSED, int NFIX = 0>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
 {
     const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / (NFIX ? NFIX : 1) : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
-    const bool n64 = (BLOCK == 256) && (AN == 64);
+    const bool n64 = (BLOCK <= 256) && (AN == 64);
 
     const int tid = threadIdx.x;
 #ifdef MRS_TIMELINE // diagnostic build (tools/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
             const DownwashConst &dc = A.dc;
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
 #if !MRS_EXACT_F32
-            if (BLOCK == 256 && AN == 64) {
+            if (BLOCK <= 256 && AN == 64) {
                 // N = 64: the env is exactly this wave.  The pair term depends only on (|dz|, dxy^2) and lands
                 // on the LOWER quadcopter of the pair, so each unordered pair is evaluated once: lane i takes
                 // the pairs (i, i+k), k = 1..31, keeps the term if the other is above, and hands it to lane
@@ -764,10 +776,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? (FUSED ? MRS_FUSED_WAVES : M
         if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
 #endif
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
+        // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
         if (A.do_adj || carry)
-            adjacency_phase<BLOCK, NFIX, (MRS_DW_CARRY != 0 && !MRS_EXACT_F32)>(A, lds_tile, tid, el, i, live, A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
-                                                              make_float4((float)p[0], (float)p[1], (float)p[2], 0.f),
-                                                              carry ? A.dw_pos + wb_base + la : nullptr, carry ? A.dw_f + wb_base + la : nullptr);
+            adjacency_phase<BLOCK, NFIX, (MRS_DW_CARRY != 0 && !MRS_EXACT_F32)>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
+                                                                              make_float4((float)p[0], (float)p[1], (float)p[2], 0.f),
+                                                                              carry ? A.dw_pos + wb_base + la : nullptr, carry ? A.dw_f + wb_base + la : nullptr);
         TL(8); // observation + adjacency
         return;
     }
@@ -841,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
         if (nw) { w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la]; }
     }
     if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
-    if (A.do_adj) adjacency_phase<BLOCK>(A, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+    if (A.do_adj) adjacency_phase<BLOCK>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
 }
 
 // packed (M,N,W) -> dense float32 (M,N,N).  N % 4 == 0: one thread per four consecutive columns (a 16-byte store;
@@ -1113,6 +1126,7 @@ struct MrsHandle {
     MrsParams P;
     int E, N, device;
     int block, epb, W;
+    int sblock;         // workgroup size of the fused step for N = 64 (MRS_STEP_BLOCK = 64 | 128 | 256 envs-as-waves per workgroup)
     double hclip;
     int *ws;            // device workspace: [0..1] two alternating contact counters, [2..2+T) contact list
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
@@ -1245,6 +1259,8 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     h->W = (n_agents + 63) / 64;
     const char *split = getenv("MRS_STEP_SPLIT");
     h->fused = (h->block == 256) && !(split && split[0] == '1');
+    h->sblock = 256;
+    if (const char *sb = getenv("MRS_STEP_BLOCK")) { const int v = atoi(sb); if (n_agents == 64 && (v == 64 || v == 128)) h->sblock = v; }
     h->dw_pos = nullptr; h->dw_f = nullptr;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
@@ -1322,7 +1338,7 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
     const int D = mrs_obs_dim(obs_fields, n_obs);
     if (D < 0) return fail(MRS_E_ARG, "bad observation field list");
     A.n_obs = n_obs; A.D = D;
-    for (int i = 0; i < n_obs; ++i) A.obs_fields[i] = obs_fields[i];
+    for (int i = 0; i < n_obs; ++i) { A.obs_fields[i] = obs_fields[i]; A.obs_code |= (unsigned)obs_fields[i] << (4 * i); }
     if (n_obs > 0 && !b->obs) A.n_obs = 0;
     A.do_adj = (b->adj != nullptr) && !std::isnan(comm_range);
     A.comm_inf = std::isinf(comm_range) && comm_range > 0;
@@ -1342,6 +1358,14 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
     if (fused && h->N == 64) hipLaunchKernelGGL((k_step<ACT, 256, true, 64>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
     else
 #endif
+    if (fused && h->sblock != 256) { // N = 64 with fewer envs (waves) per workgroup: same kernel, smaller hand-off group
+        StepArgs B = A;
+        B.epb = h->sblock / 64;
+        const int g = (h->E + B.epb - 1) / B.epb;
+        const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + 4 * sizeof(int);
+        if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true>), dim3(g), dim3(128), l, st, B);
+        else hipLaunchKernelGGL((k_step<ACT, 64, true>), dim3(g), dim3(64), l, st, B);
+    } else
     if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
     else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, A);
