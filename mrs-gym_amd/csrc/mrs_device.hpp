@@ -620,7 +620,8 @@ struct F3 {
 };
 // Returns the velocity CHANGES (dv, dw) in float32; the caller adds them to the float64 state (the fused kernel re-reads
 // that from its LDS stash afterwards, so no float64 velocity stays live across the sweeps).
-MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out)
+MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out,
+                               float *diag = nullptr)
 {
     dv_out = F3{0.f, 0.f, 0.f}; dw_out = F3{0.f, 0.f, 0.f};
     const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
@@ -720,13 +721,20 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
             }
         }
     };
-    for (int it = 0; it < P.solver_iters; it += 2) {
+    int it = 0;
+    for (; it < P.solver_iters; it += 2) {
         float moved = 0.f;
         sweep(std::false_type{}, moved);
         if (it + 1 >= P.solver_iters) break;
         sweep(std::true_type{}, moved);
+#ifdef MRS_TIMELINE // diagnostic: per lane, the first even sweep count at which it had converged
+        if (diag && diag[0] == 0.f && moved <= tol) diag[0] = (float)(it + 2);
+#endif
         if (moved <= tol) break;
     }
+#ifdef MRS_TIMELINE
+    if (diag) diag[1] = (float)(it + 2 < P.solver_iters ? it + 2 : P.solver_iters);
+#endif
     dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwx, dwy, dwz};
 }
 
@@ -742,10 +750,10 @@ MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3
 
 // The fused kernel's form: only the float32 velocity changes come back (see contact_solve_f32).
 MRS_DEV void contact_stage_delta(const MrsParams &P, const Recips &K, double pz, const double q[4], const double v[3], const double w[3],
-                                 F3 &dv, F3 &dw)
+                                 F3 &dv, F3 &dw, float *diag = nullptr)
 {
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
-    contact_solve_f32(P, K, pz, R, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw);
+    contact_solve_f32(P, K, pz, R, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, diag);
 }
 
 MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[3], const double w[3]);

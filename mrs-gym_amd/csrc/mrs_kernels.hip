@@ -287,7 +287,8 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
 // second half of the kernel with one or two waves left -- too few to hide latency (clock64 stamps: waves ended
 // between 42k and 79k ticks of a 79k-tick kernel).  Priority falling with progress (pair loop 2, controller 1,
 // pose/outputs 0) keeps them abreast: 34.3 -> 31.8 us per step.  The contact solve, the one serial stretch that
-// three waves of its workgroup wait for, runs at 3.
+// three waves of its workgroup wait for, runs at 3.  Round 2: all four levels in use (pair loop 3, controller 2,
+// forces 1, outputs 0): 29.2 -> 28.7 us; equal priorities cost +2.5 us, leaders-first +2.8 us (tools/abl_run.sh).
 // MRS_AB_PRIO: two priority classes of WORKGROUPS (by the workgroup's slot on its CU, HW_ID.tg_id).  All waves of the
 // bench swarm are resident in one round and, at equal priorities, march through load -> forces -> contact -> outputs
 // in lock-step: during the contact hand-off every SIMD is down to its solver waves.  Class A runs ahead of class B,
@@ -318,9 +319,10 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
 #define SETPRIO(both, a, b) __builtin_amdgcn_s_setprio(both)
 #endif
 #ifndef MRS_P_DW1
-#define MRS_P_DW1 2
-#define MRS_P_DW2 2
-#define MRS_P_CTRL 1
+#define MRS_P_DW1 3
+#define MRS_P_DW2 3
+#define MRS_P_CTRL 2
+#define MRS_P_FORCE 1 // rotor forces, aerodynamics, velocity integration (after the controller)
 #define MRS_P_TAIL 0
 #define MRS_P_ADJ 0
 #endif
@@ -606,6 +608,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
 #endif
             TL(2); // controller
+#ifdef MRS_P_FORCE
+            if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_FORCE);
+#endif
             // ---- Quadcopter.set_speeds (Quadcopter.py:38-45): rotor thrusts + yaw reaction torque.
             // With ACTION_TYPE=set_speeds the reference's arithmetic is float32 (float32 action tensor).
             double F[4], sumw, zt;
@@ -742,7 +747,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
                     const double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
                     const double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
+#ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/sweeps_probe.py); the run's physics is void
+                    float dg[2] = {0.f, 0.f};
+                    contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw, dg);
+                    if (wb.pid) { wb.pid[b] = dg[0]; (wb.pid + T)[b] = dg[1]; }
+#else
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw);
+#endif
                 }
                 // the float64 velocities are read again from the stash: nothing float64 is live across the sweeps
                 sp[7 * BLOCK + b] += (double)dv.x; sp[8 * BLOCK + b] += (double)dv.y; sp[9 * BLOCK + b] += (double)dv.z;

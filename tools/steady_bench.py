@@ -20,6 +20,9 @@ ATYPE = os.environ.get("ATYPE", "set_target_vel")
 pos, eul = grid_spawn(E, N)
 z = np.zeros((E, N, 3), np.float32)
 sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+if os.environ.get("NOCONTACT"):     # what the step costs without the ground: no contact hand-off, nothing to solve
+    prm = mrsgym_amd.default_params(); prm.enable_contact = 0; prm.ground_z = -1e9
+    sh.set_params(prm)
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
 acts = ActionStream(ATYPE, E, N, pos, seed=1000)
 table = [torch.from_numpy(acts(50 * k)).cuda() for k in range((ROLLIN + K * REPS) // 50 + 2)]
