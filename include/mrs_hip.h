@@ -140,6 +140,15 @@ int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, cons
 int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
              const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream);
 
+/* n_substeps consecutive MRS.step calls in ONE launch (the `n_substeps` of SURVEY.md 8b; frame-skip / on-device rollouts):
+ * substep s uses the action batch at actions + s * action_stride (0: the same actions are held, as gym wrappers that
+ * repeat an action do) and writes its observation slice at b->obs + s * obs_stride floats and its adjacency rows at
+ * b->adj + s * adj_stride words (strides may be negative: a history ring that grows downwards).  Results are those of
+ * n_substeps mrs_step calls, bit for bit; the launches are queued back to back from this one call.
+ * Host callbacks (reward_fn, done_fn, ...) cannot run between substeps: that is the caller's contract. */
+int mrs_step_n(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type, int n_substeps, int64_t action_stride,
+               const int32_t *obs_fields, int n_obs_fields, double comm_range, int64_t obs_stride, int64_t adj_stride, void *stream);
+
 /* Environment.get_X fast path for a state_fn that concatenates getters (Environment.py:84-87),
  * without stepping: used by reset()/set() -> calc_Xk (MRS.py:190, :203). */
 int mrs_observe(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs_fields, void *stream);

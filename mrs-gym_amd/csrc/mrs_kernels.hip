@@ -1384,6 +1384,29 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
 }
 
 extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
+                        const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream);
+
+// n_substeps consecutive steps from ONE host call: the launches are queued back to back on the stream (the GPU runs
+// them without a gap; what is saved is the caller's per-step work between them).  Keeping the state in registers
+// across substeps inside one launch was built and measured in round 2: wrapped in a loop, the fused kernel no longer
+// fits its 128 vector / 104 scalar registers (the compiler hoists ~50 per-lane plane addresses and the argument loads
+// out of the loop: 350-860 bytes of scratch per lane), so the substeps stay separate launches.
+extern "C" int mrs_step_n(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type, int n_substeps, int64_t action_stride,
+                          const int32_t *obs_fields, int n_obs_fields, double comm_range, int64_t obs_stride, int64_t adj_stride, void *stream)
+{
+    if (!h || !b) return fail(MRS_E_ARG, "mrs_step_n: NULL handle/buffers");
+    if (n_substeps < 1) return fail(MRS_E_ARG, "mrs_step_n: n_substeps must be >= 1");
+    MrsBuffers bb = *b;
+    for (int s = 0; s < n_substeps; ++s) {
+        const int rc = mrs_step(h, &bb, actions ? actions + (long long)s * action_stride : nullptr, action_type, obs_fields, n_obs_fields, comm_range, stream);
+        if (rc) return rc;
+        if (bb.obs) bb.obs += obs_stride;
+        if (bb.adj) bb.adj += adj_stride;
+    }
+    return 0;
+}
+
+extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
                         const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream)
 {
     if (!h || !b) return fail(MRS_E_ARG, "mrs_step: NULL handle/buffers");

@@ -533,6 +533,73 @@ class MRS(_EnvBase):
                 Xk = self.reset()
         return Xk, reward, done, info
 
+    def step_n(self, actions, n_substeps, ACTION_TYPE=None):
+        """Frame skip (extension; the `n_substeps` of SURVEY.md 8b): `n_substeps` consecutive steps -- `actions` either one
+        batch held for all of them, (E,N,adim), or one batch per substep, (S,E,N,adim) -- with the K_HOPS histories
+        advanced every substep exactly as `n_substeps` step() calls would (bit-identical X / A), but one C call for the
+        first S-1 of them and the callbacks (update / reward / info / done) run once, on the last substep, whose step()
+        return value is returned.  A NaN action skips that substep of that env (flagged like in step())."""
+        S = int(n_substeps)
+        if S < 1:
+            raise ValueError("n_substeps must be >= 1")
+        if actions is None:
+            for _ in range(S - 1):
+                self._advance(None, 0, 1, 0)
+            return self.step(None, ACTION_TYPE)
+        E, N = self.N_ENVS, self.N_AGENTS
+        a = actions if isinstance(actions, torch.Tensor) else torch.tensor(np.asarray(actions))
+        atype = ACTION_TYPE if ACTION_TYPE is not None else self.ACTION_TYPE
+        at = native.ACT.get(atype, -1) if atype is not None else -1
+        if at <= 0:
+            raise AttributeError("'Quadcopter' object has no attribute %r" % (atype,))
+        a = a.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        per = E * N * native.ACT_DIM[at]
+        if a.numel() == per:
+            seq, stride = None, 0
+        elif a.numel() == S * per:
+            seq, stride = a.reshape(S, -1), per
+        else:
+            raise ValueError("actions has %d elements, expected (%sN=%d, %d) or %d of them" % (a.numel(), "" if E == 1 else "E=%d, " % E, N, native.ACT_DIM[at], S))
+        if S > 1:
+            self._advance(a if seq is None else seq[:S - 1], at, S - 1, stride)
+        last = a if seq is None else seq[S - 1]
+        return self.step(last.reshape((E, N, -1) if E > 1 else (N, -1)), ACTION_TYPE)
+
+    def _advance(self, actions, at, n, act_stride):
+        """n steps without callbacks: history rings advanced slot by slot (they grow towards slot 0, hence the negative
+        strides), as many substeps per mrs_step_n call as fit before a ring wraps."""
+        want_A = self.RETURN_A is None or bool(self.RETURN_A)
+        xr, ar = self._Xring, self._Apacked
+        fused = self._obs.fused
+        done = 0
+        while done < n:
+            xslot = xr.next_slot()
+            aslot = ar.next_slot() if want_A else 0
+            cnt = 1
+            if fused and xr.count > 0 and (not want_A or (ar.count > 0 and ar.head == xr.head and ar.L == xr.L)):
+                cnt += min(n - done - 1, xr.head)            # slots below the new head that can be written before the wrap
+            a_ptr = None
+            if actions is not None:
+                a_ptr = actions if act_stride == 0 else actions[done:]
+            self.shard.step_n_ptr(a_ptr, at, cnt, act_stride, xr.ptr(xslot) if fused else 0, -xr._stride // 4,
+                                  ar.ptr(aslot) if want_A else 0, -ar._stride // 8, float(self.COMM_RANGE))
+            if not fused:
+                self._obs.write_into(xr.buf[xslot])
+            xr.committed()
+            if want_A:
+                ar.committed()
+                self._expand_newest_A()
+            for _ in range(cnt - 1):                          # the extra substeps of this call: slide the windows down
+                xr.head -= 1
+                xr.count = min(xr.count + 1, xr.K + 1)
+                if want_A:
+                    ar.head -= 1
+                    ar.count = min(ar.count + 1, ar.K + 1)
+                    self._expand_newest_A()
+            done += cnt
+        self.steps_since_reset += n
+        self._global_step += n
+
     def get_env(self):  # MRS.py:280-293
         return self.env
 

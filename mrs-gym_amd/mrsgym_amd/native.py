@@ -30,7 +30,7 @@ EXPORTS = [
     "mrs_abi_version", "mrs_last_error", "mrs_params_default", "mrs_params_derived", "mrs_create", "mrs_destroy",
     "mrs_set_params", "mrs_adj_words", "mrs_obs_dim", "mrs_pid_reset", "mrs_set_state", "mrs_set_state_f64",
     "mrs_step", "mrs_observe", "mrs_adjacency", "mrs_adjacency_expand", "mrs_spawn", "mrs_reynolds",
-    "mrs_raycast", "mrs_proximity", "mrs_flock_metrics", "mrs_spawn_from",
+    "mrs_raycast", "mrs_proximity", "mrs_flock_metrics", "mrs_spawn_from", "mrs_step_n",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
         L.mrs_set_state.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, C.c_int, vp, vp, vp, vp]
         L.mrs_set_state_f64.argtypes = [vp, C.POINTER(MrsBuffers), vp, vp, vp, vp, vp, vp]
         L.mrs_step.argtypes = [vp, C.POINTER(MrsBuffers), vp, C.c_int, i32p, C.c_int, C.c_double, vp]
+        L.mrs_step_n.argtypes = [vp, C.POINTER(MrsBuffers), vp, C.c_int, C.c_int, C.c_int64, i32p, C.c_int, C.c_double, C.c_int64, C.c_int64, vp]
         L.mrs_observe.argtypes = [vp, C.POINTER(MrsBuffers), i32p, C.c_int, vp]
         L.mrs_adjacency.argtypes = [vp, C.POINTER(MrsBuffers), C.c_double, vp]
         L.mrs_adjacency_expand.argtypes = [vp, vp, vp, C.c_int, vp]
@@ -297,6 +298,43 @@ class SwarmShard:
                              torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(rc, "mrs_step")
+
+    def step_n(self, actions, action_type, n_substeps, obs_out=None, adj_out=None, comm_range=float("nan")):
+        """n_substeps steps in one launch (mrs_step_n).  actions: (S,E,N,adim) for per-substep actions or (E,N,adim) held for
+        all substeps; obs_out (S,E,N,D) / adj_out (S,E,N,W): one slice per substep, substep s at index s."""
+        at = action_type if isinstance(action_type, int) else ACT.get(action_type, -1)
+        S = int(n_substeps)
+        stride = 0
+        if actions is None:
+            at = 0
+        elif at > 0:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            per = self.T * ACT_DIM[at]
+            if actions.numel() == S * per and S > 1:
+                stride = per
+            elif actions.numel() != per:
+                raise ValueError("actions has %d elements, expected (E,N,%d) or (%d,E,N,%d)" % (actions.numel(), ACT_DIM[at], S, ACT_DIM[at]))
+        b = self._buffers(obs_out, adj_out)
+        self.version += 1
+        cr = float(comm_range) if adj_out is not None else float("nan")
+        rc = self.L.mrs_step_n(self.h, C.byref(b), _ptr(actions), at, S, stride, self.obs_codes, self.n_obs if obs_out is not None else 0, cr,
+                               self.T * self.D if obs_out is not None else 0, self.T * self.W if adj_out is not None else 0, _stream(self.device))
+        if rc == -2:
+            raise AttributeError("'Quadcopter' object has no attribute %r" % (action_type,))
+        _check(rc, "mrs_step_n")
+
+    def step_n_ptr(self, actions, at, n, act_stride, obs_ptr, obs_stride, adj_ptr, adj_stride, comm_range):
+        """mrs_step_n with raw slot pointers (MRS.step_n): strides in elements, may be negative."""
+        b = self._pb
+        b.obs = obs_ptr or None
+        b.adj = adj_ptr or None
+        self.version += 1
+        rc = self.L.mrs_step_n(self.h, self._pb_ref, actions.data_ptr() if actions is not None else None, at, n, act_stride, self.obs_codes,
+                               self.n_obs if obs_ptr else 0, comm_range if adj_ptr else _NAN, obs_stride, adj_stride,
+                               torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(rc, "mrs_step_n")
 
     def observe(self, obs_out, fields=None):
         """Newest observation slice of the current state; `fields` overrides the shard's fused spec for this call only."""

@@ -297,6 +297,43 @@ def test_vectorised_envs_match_single_env_runs():
     assert "A" not in info
 
 
+def test_step_n_is_n_steps_bit_for_bit():
+    """MRS.step_n / mrs_step_n (the n_substeps of SURVEY.md 8b): S substeps from one call == S step() calls -- state, the
+    K_HOPS observation and adjacency histories (incl. across a history-ring wrap), dense and packed A, held and per-substep
+    actions; the callbacks run once, on the last substep."""
+    import mrsgym_amd
+    E, N, K = 3, 12, 2
+    pos, eul = grid_spawn(E, N, yaw_range=0.8)
+    calls = {"n": 0}
+
+    def reward_fn(**kw):
+        calls["n"] += 1
+        return 0.0
+    for fmt in ("dense", "packed"):
+        kw = dict(N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.5, START_POS=torch.from_numpy(pos), A_FORMAT=fmt,
+                  ACTION_TYPE="set_target_vel", HISTORY_SLOTS=7)
+        a_env = mrsgym_amd.make('mrs-v0', reward_fn=reward_fn, **kw)
+        b_env = mrsgym_amd.make('mrs-v0', **kw)
+        for e_ in (a_env, b_env):
+            e_.reset(ori=torch.from_numpy(eul))
+        acts = ActionStream("set_target_vel", E, N, pos, seed=8, coherent=True)
+        t = 0
+        for S, per_substep in ((1, False), (4, False), (5, True), (9, True), (3, False)):       # 22 substeps over a 7-slot ring: several wraps
+            seq = torch.from_numpy(np.stack([acts(t + s) for s in range(S)])).cuda()
+            calls["n"] = 0
+            Xa, ra, da, ia = a_env.step_n(seq if per_substep else seq[0], S)
+            assert calls["n"] == 1
+            for s in range(S):
+                Xb, rb, db, ib = b_env.step(seq[s] if per_substep else seq[0])
+            assert torch.equal(Xa, Xb) and torch.equal(ia["A"], ib["A"]), (fmt, S)
+            for name in ("pos", "quat", "vel", "angvel", "pid"):
+                assert torch.equal(torch.nan_to_num(getattr(a_env.shard, name)), torch.nan_to_num(getattr(b_env.shard, name))), name
+            assert a_env.steps_since_reset == b_env.steps_since_reset
+            t += S
+    with pytest.raises(ValueError):
+        a_env.step_n(torch.zeros(2, E, N, 3), 3)
+
+
 def test_checkpoint_roundtrip():
     import mrsgym_amd
     N = 6
