@@ -165,7 +165,7 @@ template <int BLOCK, int NFIX = 0, bool DW = false>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
                                                 uint64_t *row, float4 mine, float4 *dw_pos = nullptr, double *dw_f = nullptr)
 {
-    const bool n64 = (BLOCK <= 256) && (NFIX == 64 || A.N == 64);
+    const bool n64 = (NFIX == 64 || A.N == 64);
     if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
     else lds_tile[tid] = mine;
     if (n64) wave_lds_sync(); else __syncthreads();
@@ -339,7 +339,7 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
 // k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
 // NFIX = 64: the instantiation for N_AGENTS = 64 (one env per wave; the generic-N branches fold away), 0: any N.
 template <int ACT, int BLOCK, bool FUSED, int NFIX = 0>
-__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : 1)) void k_step(const StepArgs A)
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : (FUSED ? 4 : 1))) void k_step(const StepArgs A)
 {
     const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / (NFIX ? NFIX : 1) : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
-    const bool n64 = (BLOCK <= 256) && (AN == 64);
+    const bool n64 = (AN == 64);
 
     const int tid = threadIdx.x;
 #ifdef MRS_TIMELINE // diagnostic build (tools/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             const DownwashConst &dc = A.dc;
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
 #if !MRS_EXACT_F32
-            if (BLOCK <= 256 && AN == 64) {
+            if (AN == 64) {
                 // N = 64: the env is exactly this wave.  The pair term depends only on (|dz|, dxy^2) and lands
                 // on the LOWER quadcopter of the pair, so each unordered pair is evaluated once: lane i takes
                 // the pairs (i, i+k), k = 1..31, keeps the term if the other is above, and hands it to lane
@@ -1137,7 +1137,7 @@ struct MrsHandle {
     MrsParams P;
     int E, N, device;
     int block, epb, W;
-    int sblock;         // workgroup size of the fused step for N = 64 (MRS_STEP_BLOCK = 64 | 128 | 256 envs-as-waves per workgroup)
+    int sblock;         // workgroup size of the fused step for N = 64: 512 = eight envs (waves) per workgroup (MRS_STEP_BLOCK overrides)
     double hclip;
     int *ws;            // device workspace: [0..1] two alternating contact counters, [2..2+T) contact list
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
@@ -1270,8 +1270,11 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     h->W = (n_agents + 63) / 64;
     const char *split = getenv("MRS_STEP_SPLIT");
     h->fused = (h->block == 256) && !(split && split[0] == '1');
-    h->sblock = 256;
-    if (const char *sb = getenv("MRS_STEP_BLOCK")) { const int v = atoi(sb); if (n_agents == 64 && (v == 64 || v == 128)) h->sblock = v; }
+    // N = 64: eight envs (waves) per workgroup.  Measured at the bench size (tools/abl_sblock.sh, same build, us per step):
+    // 64 threads 32.1, 128: 30.5, 256: 29.0, 512: 27.5, 1024: 29.6 -- two workgroups of eight waves per CU pool their
+    // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
+    h->sblock = (n_agents == 64) ? 512 : 256;
+    if (const char *sb = getenv("MRS_STEP_BLOCK")) { const int v = atoi(sb); if (n_agents == 64 && (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024)) h->sblock = v; }
     h->dw_pos = nullptr; h->dw_f = nullptr;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
@@ -1373,8 +1376,17 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
         StepArgs B = A;
         B.epb = h->sblock / 64;
         const int g = (h->E + B.epb - 1) / B.epb;
-        const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + 4 * sizeof(int);
+        const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + (size_t)(h->sblock / 64) * sizeof(int);
         if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true>), dim3(g), dim3(128), l, st, B);
+        else if (h->sblock == 512) { // 74 KB of LDS per workgroup: above the 64 KB default limit of a launch
+            static bool big_lds = false; // per ACTION_TYPE instantiation; a handle is not thread-safe (include/mrs_hip.h)
+            if (!big_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); big_lds = true; }
+            hipLaunchKernelGGL((k_step<ACT, 512, true>), dim3(g), dim3(512), l, st, B);
+        } else if (h->sblock == 1024) {
+            static bool big_lds = false;
+            if (!big_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); big_lds = true; }
+            hipLaunchKernelGGL((k_step<ACT, 1024, true>), dim3(g), dim3(1024), l, st, B);
+        }
         else hipLaunchKernelGGL((k_step<ACT, 64, true>), dim3(g), dim3(64), l, st, B);
     } else
     if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
