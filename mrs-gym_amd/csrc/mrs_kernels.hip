@@ -36,10 +36,10 @@ struct StepArgs {
     Recips rc;
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
-    // N = 64 fused step: downwash carried from the previous step (library workspace, see adjacency_phase)
     DownwashConst dc;   // host-computed once per call
-    float4 *dw_pos;     // [T] float32 position the carried force belongs to (w unused)
-    double *dw_f;       // [T] the force: sum of the pair terms of Quadcopter.py:99-115
+    // Euler angles carried from the previous step's observation slice to this step's attitude controller (MRS_EUL_CARRY)
+    float4 *eul_key;    // [T] the float32 quaternion the angles were evaluated from (Object.py:92-93)
+    double *eul_ang;    // [3][T] float64 roll, pitch, yaw (Object.py:97 before the float32 truncation)
 };
 
 // Velocity planes: float64 like Bullet's state, or (MRS_VEL_F32) float32 -- what every consumer of the state reads
@@ -103,13 +103,35 @@ __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size
     b.angvel[t] = (vel_t)w[0]; (b.angvel + T)[t] = (vel_t)w[1]; (b.angvel + 2 * T)[t] = (vel_t)w[2];
 }
 
+// The attitude controller of step t+1 reads the Euler angles of the state step t left behind (Quadcopter.py:54-61 ->
+// Object.get_ori) -- the angles step t's observation slice has just evaluated for the caller's state_fn.  With
+// MRS_EUL_CARRY the slice also leaves them, in float64 and keyed by the float32 quaternion they belong to, in a library
+// workspace; the next step uses them iff every lane of the wave finds its key equal to its current float32 quaternion
+// (anything that rewrites the state in between -- set_state, spawn, reset -- simply fails the comparison) and otherwise
+// evaluates sqrt + 3 atan2 (~130 float64 instructions) itself.  Same values either way: the angles are a function of
+// the float32 quaternion alone.
+// Off by default: it pays only when the caller's observation contains the Euler angles.  With the bench's
+// state_fn = cat(pos, vel) nothing is carried and the 40 B key + angle loads per agent are pure cost (measured, same box:
+// 28.2 us per step against 27.5; tools/micro/skeleton.hip: the step's loads and stores alone take 15 us per launch, so
+// bytes are not free).
+#ifndef MRS_EUL_CARRY
+#define MRS_EUL_CARRY 0
+#endif
 // newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
-__device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
+__device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3],
+                                          float4 *eul_key = nullptr, double *eul_ang = nullptr, size_t T = 0)
 {
     bool want_euler = false;
     for (int f = 0; f < n_obs; ++f) want_euler |= (((code >> (4 * f)) & 15u) == MRS_OBS_EULER);
     Observed ob;
-    if (want_euler) observe<true, false>(p, q, v, w, ob); else observe<false, false>(p, q, v, w, ob);
+    if (want_euler) {
+        double ang[3];
+        observe<true, false>(p, q, v, w, ob, ang);
+        if (eul_key) {
+            *eul_key = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+            eul_ang[0] = ang[0]; eul_ang[T] = ang[1]; eul_ang[2 * T] = ang[2];
+        }
+    } else observe<false, false>(p, q, v, w, ob);
     int off = 0;
     for (int f = 0; f < n_obs; ++f) {
         switch ((code >> (4 * f)) & 15u) {
@@ -122,9 +144,10 @@ __device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, co
         }
     }
 }
-__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
+__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3],
+                                          float4 *eul_key = nullptr, double *eul_ang = nullptr)
 {
-    write_obs(A.obs_code, A.n_obs, o, p, q, v, w);
+    write_obs(A.obs_code, A.n_obs, o, p, q, v, w, eul_key, eul_ang, (size_t)A.T);
 }
 
 // bit-packed adjacency row of agent i from the env's LDS position tile (MRS.calc_A, MRS.py:117-124):
@@ -159,14 +182,45 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// N = 64 position tile: an env is one wave, its 64 float32 positions sit in LDS as three arrays x[128], y[128], z[128]
+// (each STORED TWICE back to back so that "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant
+// offset per unrolled k) inside the env's 128-float4 slot of lds_tile.  Separate arrays, not float4 records, so that one
+// ds_read2_b32 puts the coordinates of neighbours k and k+1 into an aligned register pair -- the operand form of the
+// packed float32 instructions (v_pk_add/mul/fma_f32: two IEEE operations for the issue cost of one, measured in
+// tools/micro/valu_rates2.hip), which the pair loops below use for everything that is not a transcendental or a compare.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
+__device__ __forceinline__ float *tile64(float4 *lds_tile, int el) { return reinterpret_cast<float *>(lds_tile + el * 128); }
+__device__ __forceinline__ void tile64_write(float4 *lds_tile, int el, int i, float x, float y, float z)
+{
+    float *t = tile64(lds_tile, el);
+    t[i] = t[64 + i] = x; t[128 + i] = t[192 + i] = y; t[256 + i] = t[320 + i] = z;
+}
+// the differences to neighbours k and k+1 of the lane whose tile pointer (already offset by the lane) is t
+__device__ __forceinline__ void tile64_rel2(const float *t, int k, f2 mx, f2 my, f2 mz, f2 &rx, f2 &ry, f2 &rz)
+{
+    rx = pk_sub(f2{t[k], t[k + 1]}, mx); ry = pk_sub(f2{t[128 + k], t[128 + k + 1]}, my); rz = pk_sub(f2{t[256 + k], t[256 + k + 1]}, mz);
+}
+
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
-template <int BLOCK, int NFIX = 0, bool DW = false>
+template <int BLOCK, int NFIX = 0>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
-                                                uint64_t *row, float4 mine, float4 *dw_pos = nullptr, double *dw_f = nullptr)
+                                                uint64_t *row, float4 mine)
 {
     const bool n64 = (NFIX == 64 || A.N == 64);
-    if (n64) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = mine; // doubled tile: see k_step
+    if (n64) tile64_write(lds_tile, el, i, mine.x, mine.y, mine.z);
     else lds_tile[tid] = mine;
     if (n64) wave_lds_sync(); else __syncthreads();
     if (n64) {
@@ -175,109 +229,116 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
         // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
         // it is relative bit 64-k; k = 32 is tested by both ends.  One 64-bit rotate by the lane index at
         // the end turns relative into absolute columns.
-        //
-        // DW: the same loop also evaluates the NEXT step's downwash (Quadcopter.py:99-115 reads the pre-step
-        // positions of step t+1, which are the post-step positions this loop is looking at): neighbour read, the
-        // three differences and dxy^2 are shared with the range test, and the next step starts without its own
-        // pair loop.  The force is stored with the float32 position it belongs to; a step whose positions differ
-        // from that (set_state, reset, a restored checkpoint, a caller writing the buffers) recomputes it.
+        // (Round 2 experiment, removed: evaluating the NEXT step's downwash in this loop -- it shares the neighbour
+        // read and the differences -- and carrying the force to the next launch.  31.6 against 30.3 us per step, and
+        // 28.8 against 27.6 after the other changes of the round: the work moves from the start of the kernel, where
+        // issue slots are idle while the state loads are in flight, to its end, where none are.)
         if (live) {
             const int lane = tid & 63;
-            const float4 *nb = lds_tile + el * 128 + lane;
+            const float *t = tile64(lds_tile, el) + lane;
             const int lane4 = lane << 2;
             // own verdicts at bit k of `lo`; the SAME word travels to lane i+k, whose verdicts from below
             // collect in `hr` at bit k too and are mirrored into place (relative bit 64-k) by one v_bfrev at
             // the end: one select and two ORs per pair, no per-pair shifts
             uint32_t lo = 0, hr = 0, top = 0;
-            const bool want_dw = DW && dw_pos != nullptr;
-            float acc32 = 0.f, pend = 0.f;
-            double dacc = 0.;
             // The range threshold lives in a VECTOR register for the loop (comm_range = inf arrives as thr = +inf from
             // the host).  As a kernel argument it is re-read from the argument segment inside every pair once scalar
             // registers are short -- s_load + s_waitcnt lgkmcnt(0), which also drains the pair's LDS read and every
             // cross-lane transfer in flight: the loop then runs one pair per memory round trip.
             float thr = thr_s;
             asm volatile("" : "+v"(thr));
-            auto pairs = [&](auto with_dw) {
-                DownwashRegs dr = {0.f, 0.f, 0.f};
-                if (with_dw) dr = downwash_regs(A.dc);
-#pragma unroll
-                for (int k = 1; k <= 32; ++k) {
-                    const float4 pj = nb[k];
-                    const float rx = f32sub(pj.x, mine.x), ry = f32sub(pj.y, mine.y), rz = f32sub(pj.z, mine.z);
-                    const float d2xy = f32fma(ry, ry, f32mul(rx, rx));
-                    const float d2 = f32fma(rz, rz, d2xy);
-                    const bool close = d2 <= thr;
-                    if (k < 32) {
-                        const uint32_t bit = close ? (1u << k) : 0u;
-                        lo |= bit;
-                        hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
-                    } else {
-                        top = close ? 1u : 0u; // relative bit 32: tested by both ends
-                    }
-                    if (with_dw) { // same sequence of operations as downwash_ring64: bit-identical force
-                        if (k < 32) {
-                            const float F = downwash_mag2(d2xy, fabsf(rz), dr.dw2, dr.dw3, dr.lg);
-                            const bool above = rz > 0.f;
-                            const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
-                            const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
-                            // the term handed over by lane i-k is added one pair LATE (its cross-lane round trip then overlaps
-                            // the next pair's arithmetic); the sums are anchored so that they are formed here and not sunk to
-                            // the end of the loop, which would keep all 31 handed-over terms alive (spills)
-                            acc32 = f32add(f32add(acc32, pend), f_self);
-                            asm volatile("" : "+v"(acc32));
-                            pend = f_in;
-                            if ((k & 7) == 0) { dacc += (double)acc32; acc32 = 0.f; }
-                        } else {
-                            acc32 = f32add(f32add(acc32, pend), rz > 0.f ? downwash_mag2(d2xy, rz, dr.dw2, dr.dw3, dr.lg) : 0.f);
-                            dacc += (double)acc32;
-                        }
-                    }
-                }
-            };
             // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
-            if (DW && want_dw) pairs(std::true_type{}); else if (!comm_inf) pairs(std::false_type{});
+            if (!comm_inf) {
+                const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
+                auto verdict = [&](int k, float d2) {
+                    const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
+                    lo |= bit;
+                    hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
+                };
+#pragma unroll
+                for (int k = 1; k < 31; k += 2) { // two neighbours per pass: d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
+                    f2 rx, ry, rz;
+                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                    verdict(k, d2.x);
+                    verdict(k + 1, d2.y);
+                }
+                {   // k = 31, and k = 32: relative bit 32 is tested by both ends
+                    f2 rx, ry, rz;
+                    tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                    verdict(31, d2.x);
+                    top = d2.y <= thr ? 1u : 0u;
+                }
+            }
             const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
             const uint64_t rel = comm_inf ? ~1ull : (((uint64_t)hi << 32) | lo);
             if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
-            if (DW && want_dw) { *dw_pos = make_float4(mine.x, mine.y, mine.z, 0.f); *dw_f = dacc; }
         }
     } else if (live) {
         adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], row);
     }
 }
 
-// The downwash of an N = 64 env from its LDS tile (doubled layout), evaluated once per unordered pair: see k_step.
-// The fused adjacency loop above carries the identical sequence of operations.
-__device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, float my, float mz, int lane4, const DownwashConst &dc)
+// The downwash of an N = 64 env from its LDS tile (see tile64_write), evaluated once per unordered pair: see k_step.
+// t = the env's tile + lane.  Two neighbours per pass through the packed float32 instructions; the reciprocals, the
+// exponential and the selects stay per neighbour.  Per pair operation for operation the arithmetic of downwash_mag2;
+// the terms a lane keeps and the terms handed to it are summed separately (float32, flushed to float64 every 8 pairs).
+__device__ __forceinline__ double downwash_ring64(const float *t, float mx_, float my_, float mz_, int lane4, const DownwashConst &dc)
 {
     const DownwashRegs dr = downwash_regs(dc);
-    float acc32 = 0.f, pend = 0.f;
+    const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
+    const f2 lg = splat(dr.lg), ce = splat(-0.5f * 1.44269504088896341f);
+    f2 acc = {0.f, 0.f}; // .x: the terms this lane keeps, .y: the terms handed to it -- one packed add per pair
+    float pend = 0.f;
     double dacc = 0.;
-#pragma unroll
-    for (int k = 1; k < 32; ++k) {
-        const float4 pj = nb[k];
-        const float rx = f32sub(pj.x, mx), ry = f32sub(pj.y, my), rz = f32sub(pj.z, mz);
-        const float F = downwash_mag2(f32fma(ry, ry, f32mul(rx, rx)), fabsf(rz), dr.dw2, dr.dw3, dr.lg); // 0 when dz == 0
-        const bool above = rz > 0.f;
-        const float f_self = above ? F : 0.f, f_other = above ? 0.f : F;
+    // m = |term| of the pair (this lane, lane + k); rz = the neighbour's height above this lane
+    auto deliver = [&](int k, float m, float rz, float d2) {
+        const bool near = d2 < 100.f;                          // delta_xy < 10 (Quadcopter.py:106)
+        const float f_self = (rz > 0.f && near) ? -m : 0.f;    // the neighbour is above: the term is this lane's
+        const float f_other = (rz < 0.f && near) ? -m : 0.f;   // below: the term is the neighbour's (0 when dz == 0)
         // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
         const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
-        acc32 = f32add(f32add(acc32, pend), f_self); // the handed-over term joins one pair late: see adjacency_phase
-        asm volatile("" : "+v"(acc32));              // (without the anchor two ACTION_TYPEs spill; measured equal otherwise)
+        // the term handed over by lane i-k is added one pair LATE (its cross-lane round trip then overlaps the next
+        // pair's arithmetic); the sums are anchored so that they are formed here and not sunk to the end of the loop,
+        // which would keep all 31 handed-over terms alive (without the anchor two ACTION_TYPEs spill)
+        acc = acc + f2{f_self, pend};
+        asm volatile("" : "+v"(acc));
         pend = f_in;
-        if ((k & 7) == 0) { dacc += (double)acc32; acc32 = 0.f; } // short float32 partial sums
+        if ((k & 7) == 0) { dacc += (double)f32add(acc.x, acc.y); acc = f2{0.f, 0.f}; } // short float32 partial sums
+    };
+    // |dz| enters only through the abs operand modifier of v_rcp_f32 / v_fma_f32 (the packed forms have none)
+    auto mag2 = [&](f2 d2, f2 rz) {
+        const f2 rdz = {__builtin_amdgcn_rcpf(fabsf(rz.x)), __builtin_amdgcn_rcpf(fabsf(rz.y))};
+        const f2 rb = {__builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.x), dr.dw3)), __builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.y), dr.dw3))};
+        const f2 arg = pk_fma(pk_mul(pk_mul(d2, rb), rb), ce, lg);
+        const f2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+        return pk_mul(pk_mul(rdz, rdz), ex);
+    };
+#pragma unroll
+    for (int k = 1; k < 31; k += 2) {
+        f2 rx, ry, rz;
+        tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+        const f2 m = mag2(d2, rz);
+        deliver(k, m.x, rz.x, d2.x);
+        deliver(k + 1, m.y, rz.y, d2.y);
     }
-    const float4 pj = nb[32];
-    const float rx = f32sub(pj.x, mx), ry = f32sub(pj.y, my), rz = f32sub(pj.z, mz);
-    acc32 = f32add(f32add(acc32, pend), rz > 0.f ? downwash_mag2(f32fma(ry, ry, f32mul(rx, rx)), rz, dr.dw2, dr.dw3, dr.lg) : 0.f);
-    dacc += (double)acc32;
+    {   // k = 31, and the antipode k = 32, which both ends evaluate (each keeps its own term)
+        f2 rx, ry, rz;
+        tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+        const f2 m = mag2(d2, rz);
+        deliver(31, m.x, rz.x, d2.x);
+        acc = acc + f2{(rz.y > 0.f && d2.y < 100.f) ? -m.y : 0.f, pend};
+        dacc += (double)f32add(acc.x, acc.y);
+    }
     return dacc;
 }
 
 // ------------------------------------------------------------------------------------ step kernel
 #ifndef MRS_DEFER_LOADS
-#define MRS_DEFER_LOADS 0
+#define MRS_DEFER_LOADS 1 // measured at 512-thread workgroups: 27.5 -> 27.2 us per step (time to the first position 7.8k -> 6.7k ticks)
 #endif
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
@@ -298,9 +359,6 @@ __device__ __forceinline__ double downwash_ring64(const float4 *nb, float mx, fl
 #endif
 #ifndef MRS_NFIX64
 #define MRS_NFIX64 0
-#endif
-#ifndef MRS_DW_CARRY
-#define MRS_DW_CARRY 0 // measured: 31.6 vs 30.3 us per step (the start of the kernel has idle issue slots while the state loads are in flight, its tail has none)
 #endif
 #ifndef MRS_EARLY_TAIL
 #define MRS_EARLY_TAIL 0
@@ -393,30 +451,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         load_state(wb, la, T, p, q, v, w);
 #endif
     }
+    // angles carried from the previous step's observation slice (see MRS_EUL_CARRY)
+    constexpr bool EUL = MRS_EUL_CARRY && FUSED && (ACT >= MRS_ACT_TARGET_ACCEL);
+    float4 ekey = make_float4(0.f, 0.f, 0.f, 0.f);
+    double eang[3] = {0, 0, 0};
+    if (EUL && A.eul_key != nullptr && live) {
+        ekey = (A.eul_key + wb_base)[la];
+        const double *ea = A.eul_ang + wb_base;
+        eang[0] = ea[la]; eang[1] = (ea + T)[la]; eang[2] = (ea + 2 * T)[la];
+    }
 #if MRS_DEFER_LOADS
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    // N = 64, fused: the downwash of this step was evaluated by the previous step's adjacency loop (adjacency_phase)
-    // and is valid iff it was computed from exactly these float32 positions; otherwise the env runs its own pair loop.
-    bool have_dw = false;
     double downwash_acc = 0;
-#if MRS_DW_CARRY && !MRS_EXACT_F32
-    const bool carry = FUSED && n64 && A.dw_pos != nullptr && ACT != MRS_ACT_NONE;
-    if (carry) {
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) { c = (A.dw_pos + wb_base)[la]; downwash_acc = (A.dw_f + wb_base)[la]; }
-        const bool stale = live && !(c.x == (float)p[0] && c.y == (float)p[1] && c.z == (float)p[2]);
-        have_dw = __builtin_amdgcn_ballot_w64(stale) == 0; // the wave is the env
-        if (!have_dw) downwash_acc = 0;
-    }
-#else
-    const bool carry = false;
-#endif
-    if (n64) {
-        if (!have_dw) lds_tile[el * 128 + i] = lds_tile[el * 128 + 64 + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
-    } else {
-        lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
-    }
+    // N = 64 (one env per wave): the three-array tile of the packed pair loop (tile64_write); any other N, and the
+    // MRS_EXACT_F32 build's all-pairs loop: one float4 per agent
+    const bool tile_soa = n64 && !MRS_EXACT_F32;
+    if (tile_soa) tile64_write(lds_tile, el, i, (float)p[0], (float)p[1], (float)p[2]);
+    else lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
 #if MRS_DEFER_LOADS
     // The rest of the state is first needed by the controller: issued only now, behind the positions of EVERY wave
     // (all 4096 waves issue at once; issued up front, these 21 MB would be served before the last wave's position)
@@ -527,11 +579,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // i+k (one ds_bpermute) if the other is below; k = 32 pairs lanes with their antipode, each
                 // side evaluating its own.  32 evaluations per lane instead of 64.  (`doit` is uniform per
                 // env, so the whole wave is here.)
-                if (!have_dw) {
-                    const int lane = tid & 63;
-                    // nb[k] = neighbour (lane + k) mod 64, no wrap; lane << 2 = ds_bpermute byte address of this lane
-                    downwash_acc = downwash_ring64(lds_tile + el * 128 + lane, mx, my, mz, lane << 2, A.dc);
-                }
+                const int lane = tid & 63;
+                // tile + lane: neighbour (lane + k) mod 64 at offset k, no wrap; lane << 2 = ds_bpermute byte address of this lane
+                downwash_acc = downwash_ring64(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc);
             } else
 #endif
             {
@@ -583,7 +633,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             TL(20); // outer loop of the cascade (pos/vel control)
             Observed ob;
             M3 R; // from_euler(float32 euler read-back): only the PID modes use it
-            if (NEEDS_PID) observe_ctrl(p, q, v, w, ob, R); else observe<true, true>(p, q, v, w, ob);
+            if (NEEDS_PID) {
+                bool have_eul = false;
+                if (EUL && A.eul_key != nullptr) {
+                    const bool stale = live && !(ekey.x == (float)q[0] && ekey.y == (float)q[1] && ekey.z == (float)q[2] && ekey.w == (float)q[3]);
+                    have_eul = __builtin_amdgcn_ballot_w64(stale) == 0;
+                }
+                if (have_eul) observe_ctrl(p, q, v, w, ob, R, eang); else observe_ctrl(p, q, v, w, ob, R);
+            } else observe<true, true>(p, q, v, w, ob);
             TL(21); // read-back + rotation matrices
             if (NEEDS_PID) {
                 float *g = wb.pid + la;
@@ -784,14 +841,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         }
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         TL(7); // pose + store
-        if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+        if (A.b.obs && live && A.n_obs > 0)
+            write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
 #endif
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
-        if (A.do_adj || carry)
-            adjacency_phase<BLOCK, NFIX, (MRS_DW_CARRY != 0 && !MRS_EXACT_F32)>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
-                                                                              make_float4((float)p[0], (float)p[1], (float)p[2], 0.f),
-                                                                              carry ? A.dw_pos + wb_base + la : nullptr, carry ? A.dw_f + wb_base + la : nullptr);
+        if (A.do_adj)
+            adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)AW,
+                                         make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
         TL(8); // observation + adjacency
         return;
     }
@@ -1143,8 +1200,8 @@ struct MrsHandle {
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
     bool fused;         // one-launch step (256-thread workgroups; MRS_STEP_SPLIT=1 keeps the three-launch form)
     unsigned step_parity;
-    float4 *dw_pos;     // device workspace, N = 64 fused step: downwash carried between steps (see adjacency_phase):
-    double *dw_f;       //   the float32 position it was evaluated at, and the force
+    float4 *eul_key;    // device workspace, fused step: Euler angles carried from a step's observation slice to the next
+    double *eul_ang;    //   step's attitude controller (see MRS_EUL_CARRY): float32 quaternion key [T], float64 angles [3][T]
 };
 
 static thread_local char g_err[256] = "";
@@ -1243,12 +1300,6 @@ extern "C" int mrs_set_params(MrsHandle *h, const MrsParams *params)
     double d[7];
     mrs_params_derived(params, d);
     h->hclip = d[6];
-    if (h->dw_pos) { // a carried downwash force belongs to the old coefficients: forget it
-        DeviceGuard dg(h->device);
-        hipError_t e = hipMemset(h->dw_pos, 0xFF, (size_t)h->E * h->N * sizeof(float4));
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) return hipfail(e, "mrs_set_params");
-    }
     return 0;
 }
 
@@ -1275,7 +1326,6 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
     h->sblock = (n_agents == 64) ? 512 : 256;
     if (const char *sb = getenv("MRS_STEP_BLOCK")) { const int v = atoi(sb); if (n_agents == 64 && (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024)) h->sblock = v; }
-    h->dw_pos = nullptr; h->dw_f = nullptr;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
@@ -1290,19 +1340,19 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
-    h->dw_pos = nullptr; h->dw_f = nullptr;
-    if (e == hipSuccess && h->fused && n_agents == 64 && MRS_DW_CARRY) {
+    h->eul_key = nullptr; h->eul_ang = nullptr;
+    if (e == hipSuccess && h->fused && MRS_EUL_CARRY) {
         const size_t T = (size_t)n_envs * n_agents;
-        e = hipMalloc((void **)&h->dw_pos, T * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->dw_f, T * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(h->dw_pos, 0xFF, T * sizeof(float4)); // NaN positions: nothing carried yet
+        e = hipMalloc((void **)&h->eul_key, T * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->eul_ang, 3 * T * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(h->eul_key, 0xFF, T * sizeof(float4)); // NaN keys: nothing carried yet
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     if (e != hipSuccess) {
         if (h->ws) (void)hipFree(h->ws);
         if (h->cs) (void)hipFree(h->cs);
-        if (h->dw_pos) (void)hipFree(h->dw_pos);
-        if (h->dw_f) (void)hipFree(h->dw_f);
+        if (h->eul_key) (void)hipFree(h->eul_key);
+        if (h->eul_ang) (void)hipFree(h->eul_ang);
         (void)hipSetDevice(cur);
         delete h;
         return hipfail(e, "mrs_create workspace");
@@ -1315,12 +1365,12 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
-    if (h->ws || h->cs || h->dw_pos || h->dw_f) {
+    if (h->ws || h->cs || h->eul_key || h->eul_ang) {
         DeviceGuard dg(h->device);
+        if (h->eul_key) (void)hipFree(h->eul_key);
+        if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->ws) (void)hipFree(h->ws);
         if (h->cs) (void)hipFree(h->cs);
-        if (h->dw_pos) (void)hipFree(h->dw_pos);
-        if (h->dw_f) (void)hipFree(h->dw_f);
     }
     delete h;
 }
@@ -1345,7 +1395,7 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
         c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
         c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
         c.lg_alpha = (float)std::log2((double)c.c_alpha);
-        A.dw_pos = h->dw_pos; A.dw_f = h->dw_f;
+        A.eul_key = h->eul_key; A.eul_ang = h->eul_ang;
     }
     A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
     A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf); A.rc.inv_dt = 1.0 / h->P.dt;
