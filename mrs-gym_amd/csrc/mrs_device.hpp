@@ -623,6 +623,9 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
 struct F3 {
     float x, y, z;
 };
+// two float32 in an aligned register pair: the operand of the packed instructions (v_pk_fma_f32: two fused
+// multiply-adds for the issue cost of one, tools/micro/valu_rates2.hip)
+typedef float F2 __attribute__((ext_vector_type(2)));
 // Returns the velocity CHANGES (dv, dw) in float32; the caller adds them to the float64 state (the fused kernel re-reads
 // that from its LDS stash afterwards, so no float64 velocity stays live across the sweeps).
 MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out,
@@ -649,7 +652,9 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     // Branch-free: every lane prepares all four rim points; a point that is not within the contact threshold gets
     // zero effective masses, which turns its three rows into exact no-ops (impulses stay 0) -- no per-point
     // exec-mask round trips in the sweeps and nothing to zero-initialise.
-    F3 r[4], an[4], ax[4], ay[4];
+    F3 r[4];
+    F2 anxy[4], axxy[4], ayxy[4]; // x, y of the angular responses as pairs: dw.xy += a.xy * dl is one packed fma
+    float anz[4], axz[4], ayz[4];
     const double rdt = K.inv_dt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -663,13 +668,14 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
         const float rz = (float)rzd; // lever z rounded once from float64 (as the oracle's gap)
         r[k] = F3{rx, ry, rz};
         // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
-        an[k] = F3{Ixx * ry - Ixy * rx, Ixy * ry - Iyy * rx, Ixz * ry - Iyz * rx};
-        ax[k] = F3{Ixy * rz - Ixz * ry, Iyy * rz - Iyz * ry, Iyz * rz - Izz * ry};
-        ay[k] = F3{-Ixx * rz + Ixz * rx, -Ixy * rz + Iyz * rx, -Ixz * rz + Izz * rx};
+        const F3 an = {Ixx * ry - Ixy * rx, Ixy * ry - Iyy * rx, Ixz * ry - Iyz * rx};
+        const F3 ax = {Ixy * rz - Ixz * ry, Iyy * rz - Iyz * ry, Iyz * rz - Izz * ry};
+        const F3 ay = {-Ixx * rz + Ixz * rx, -Ixy * rz + Iyz * rx, -Ixz * rz + Izz * rx};
+        anxy[k] = F2{an.x, an.y}; anz[k] = an.z; axxy[k] = F2{ax.x, ax.y}; axz[k] = ax.z; ayxy[k] = F2{ay.x, ay.y}; ayz[k] = ay.z;
         // effective masses 1 / (1/m + (r x d) . Iw (r x d))
-        const float kn = __builtin_amdgcn_rcpf(im + (ry * an[k].x - rx * an[k].y));
-        const float kx = __builtin_amdgcn_rcpf(im + (rz * ax[k].y - ry * ax[k].z));
-        const float ky = __builtin_amdgcn_rcpf(im + (rx * ay[k].z - rz * ay[k].x));
+        const float kn = __builtin_amdgcn_rcpf(im + (ry * an.x - rx * an.y));
+        const float kx = __builtin_amdgcn_rcpf(im + (rz * ax.y - ry * ax.z));
+        const float ky = __builtin_amdgcn_rcpf(im + (rx * ay.z - rz * ay.x));
         Kn[k] = act ? kn : 0.f; Kx[k] = act ? kx : 0.f; Ky[k] = act ? ky : 0.f;
         const double vrel0 = v.z + (w.x * (double)ry - w.y * (double)rx);
         // Bullet-style rhs: open gap -> let the point close it this step; penetration -> erp push-out
@@ -686,7 +692,8 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
         c0x[k] = v0x + (w0y * r[k].z - w0z * r[k].y);
         c0y[k] = v0y + (w0z * r[k].x - w0x * r[k].z);
     }
-    float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;
+    float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwz = 0.f;
+    F2 dwxy = {0.f, 0.f};
     // the sweeps gain ~1.5 digits each (measured on the oracle); a lane stops once a whole sweep moved no
     // impulse by more than 1e-7 of the resting impulse m g dt -- float32 cannot resolve less anyway --
     // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle).
@@ -697,32 +704,32 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
         for (int k = 0; k < 4; ++k) {
             const float rx = r[k].x, ry = r[k].y, rz = r[k].z;
             { // normal: u = (ry, -rx, 0)
-                const float dvn = __builtin_fmaf(-dwy, rx, __builtin_fmaf(dwx, ry, dvz));
+                const float dvn = __builtin_fmaf(-dwxy.y, rx, __builtin_fmaf(dwxy.x, ry, dvz));
                 const float nl = fmaxf(__builtin_fmaf(Kn[k], rhs[k] - dvn, ln[k]), 0.f);
                 const float dl = nl - ln[k];
                 ln[k] = nl;
                 if (track) moved = fmaxf(moved, fabsf(dl));
                 dvz = __builtin_fmaf(dl, im, dvz);
-                dwx = __builtin_fmaf(an[k].x, dl, dwx); dwy = __builtin_fmaf(an[k].y, dl, dwy); dwz = __builtin_fmaf(an[k].z, dl, dwz);
+                dwxy = __builtin_elementwise_fma(anxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(anz[k], dl, dwz);
             }
             const float lim = mu * ln[k];
             { // friction x: u = (0, rz, -ry)
-                const float vt = __builtin_fmaf(-dwz, ry, __builtin_fmaf(dwy, rz, c0x[k] + dvx));
+                const float vt = __builtin_fmaf(-dwz, ry, __builtin_fmaf(dwxy.y, rz, c0x[k] + dvx));
                 const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Kx[k], vt, lx[k]), -lim, lim); // friction pyramid: one v_med3_f32
                 const float dl = nl - lx[k];
                 lx[k] = nl;
                 if (track) moved = fmaxf(moved, fabsf(dl));
                 dvx = __builtin_fmaf(dl, im, dvx);
-                dwx = __builtin_fmaf(ax[k].x, dl, dwx); dwy = __builtin_fmaf(ax[k].y, dl, dwy); dwz = __builtin_fmaf(ax[k].z, dl, dwz);
+                dwxy = __builtin_elementwise_fma(axxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(axz[k], dl, dwz);
             }
             { // friction y: u = (-rz, 0, rx)
-                const float vt = __builtin_fmaf(-dwx, rz, __builtin_fmaf(dwz, rx, c0y[k] + dvy));
+                const float vt = __builtin_fmaf(-dwxy.x, rz, __builtin_fmaf(dwz, rx, c0y[k] + dvy));
                 const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Ky[k], vt, ly[k]), -lim, lim);
                 const float dl = nl - ly[k];
                 ly[k] = nl;
                 if (track) moved = fmaxf(moved, fabsf(dl));
                 dvy = __builtin_fmaf(dl, im, dvy);
-                dwx = __builtin_fmaf(ay[k].x, dl, dwx); dwy = __builtin_fmaf(ay[k].y, dl, dwy); dwz = __builtin_fmaf(ay[k].z, dl, dwz);
+                dwxy = __builtin_elementwise_fma(ayxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(ayz[k], dl, dwz);
             }
         }
     };
@@ -740,7 +747,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 #ifdef MRS_TIMELINE
     if (diag) diag[1] = (float)(it + 2 < P.solver_iters ? it + 2 : P.solver_iters);
 #endif
-    dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwx, dwy, dwz};
+    dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwxy.x, dwxy.y, dwz};
 }
 
 MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
