@@ -21,16 +21,19 @@
 using namespace mrs;
 
 // ------------------------------------------------------------------------------------------ args
+// Member order = order of first use.  The kernel reads its arguments through the scalar cache, which is cold when a
+// launch starts: every 64-byte line of this struct is a memory round trip that all waves of the launch wait for before
+// they can issue their first load.  The sizes and the pointers of the first loads share the first line; the physics
+// constants (360 B, first needed by the controller) come last.
 struct StepArgs {
-    MrsParams P;
-    MrsBuffers b;
+    int E, N, T, epb, D, W;
     const float *actions;
     const uint8_t *mask;
-    int E, N, T, epb;
-    int n_obs, D;
+    MrsBuffers b;
+    int n_obs;
     int obs_fields[MRS_OBS_MAX_FIELDS];
     unsigned obs_code; // the same field list, 4 bits per field (one scalar instead of an array in the argument segment)
-    int do_adj, comm_inf, W;
+    int do_adj, comm_inf;
     float d2_thresh;
     double hclip;
     Recips rc;
@@ -40,6 +43,7 @@ struct StepArgs {
     // Euler angles carried from the previous step's observation slice to this step's attitude controller (MRS_EUL_CARRY)
     float4 *eul_key;    // [T] the float32 quaternion the angles were evaluated from (Object.py:92-93)
     double *eul_ang;    // [3][T] float64 roll, pitch, yaw (Object.py:97 before the float32 truncation)
+    MrsParams P;
 };
 
 // Velocity planes: float64 like Bullet's state, or (MRS_VEL_F32) float32 -- what every consumer of the state reads
@@ -121,6 +125,12 @@ __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size
 __device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3],
                                           float4 *eul_key = nullptr, double *eul_ang = nullptr, size_t T = 0)
 {
+    // state_fn = cat(pos, vel) (README.md:28-29, the bench's): the 24-byte row as three 8-byte stores instead of six
+    if (n_obs == 2 && code == (MRS_OBS_POS | (MRS_OBS_VEL << 4)) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0 && !eul_key) {
+        float2 *o2 = reinterpret_cast<float2 *>(o);
+        o2[0] = make_float2((float)p[0], (float)p[1]); o2[1] = make_float2((float)p[2], (float)v[0]); o2[2] = make_float2((float)v[1], (float)v[2]);
+        return;
+    }
     bool want_euler = false;
     for (int f = 0; f < n_obs; ++f) want_euler |= (((code >> (4 * f)) & 15u) == MRS_OBS_EULER);
     Observed ob;
@@ -284,7 +294,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
 // t = the env's tile + lane.  Two neighbours per pass through the packed float32 instructions; the reciprocals, the
 // exponential and the selects stay per neighbour.  Per pair operation for operation the arithmetic of downwash_mag2;
 // the terms a lane keeps and the terms handed to it are summed separately (float32, flushed to float64 every 8 pairs).
-__device__ __forceinline__ double downwash_ring64(const float *t, float mx_, float my_, float mz_, int lane4, const DownwashConst &dc)
+// hook(j), j = 0..14, runs ahead of the j-th pass: k_step spreads the state loads the loop does not need over the passes.
+template <class Hook>
+__device__ __forceinline__ double downwash_ring64(const float *t, float mx_, float my_, float mz_, int lane4, const DownwashConst &dc, Hook &&hook)
 {
     const DownwashRegs dr = downwash_regs(dc);
     const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
@@ -317,6 +329,7 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
     };
 #pragma unroll
     for (int k = 1; k < 31; k += 2) {
+        hook(k >> 1);
         f2 rx, ry, rz;
         tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
         const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
@@ -340,6 +353,9 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 #ifndef MRS_DEFER_LOADS
 #define MRS_DEFER_LOADS 1 // measured at 512-thread workgroups: 27.5 -> 27.2 us per step (time to the first position 7.8k -> 6.7k ticks)
 #endif
+#ifndef MRS_LATE_LOADS
+#define MRS_LATE_LOADS 1
+#endif
 #ifndef MRS_MIN_WAVES
 #define MRS_MIN_WAVES 1 // __launch_bounds__ 2nd argument = minimum waves per SIMD (caps VGPRs at 512/this)
 #endif
@@ -359,9 +375,6 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 #endif
 #ifndef MRS_NFIX64
 #define MRS_NFIX64 0
-#endif
-#ifndef MRS_EARLY_TAIL
-#define MRS_EARLY_TAIL 0
 #endif
 #ifndef MRS_PA_DW
 #define MRS_PA_DW 3
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const long long t_start = clock64();
     float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
 #define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
+    if (tl && (tid & 63) == 0) tl[11] = (float)(t_start & 0xFFFFFF); // start of the wave on the (per-XCD) counter, for the launch stagger
 #elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/isa_sections.py)
 #define TL(k) asm volatile("; MRS_MARK " #k)
 #else
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         load_state(wb, la, T, p, q, v, w);
 #endif
     }
+    TL(9); // kernel arguments arrived, first loads issued
     // angles carried from the previous step's observation slice (see MRS_EUL_CARRY)
     constexpr bool EUL = MRS_EUL_CARRY && FUSED && (ACT >= MRS_ACT_TARGET_ACCEL);
     float4 ekey = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -469,11 +484,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool tile_soa = n64 && !MRS_EXACT_F32;
     if (tile_soa) tile64_write(lds_tile, el, i, (float)p[0], (float)p[1], (float)p[2]);
     else lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    TL(10); // positions arrived and staged
+    // MRS_LATE_LOADS (N = 64): the ten remaining state words are not even issued here but one per pass of the pair loop
+    // (downwash_ring64's hook).  All 16 waves of a CU reach this point together and the CU's address unit takes ~16
+    // cycles per 512-byte load instruction: issued in one go, the last wave waits ~2.5k cycles (clock64 stamps) for
+    // its tenth load to be ACCEPTED before it can start the loop; spread out, the loads ride along with the arithmetic.
+    const bool late_loads = MRS_LATE_LOADS && FUSED && tile_soa && ACT != MRS_ACT_NONE;
 #if MRS_DEFER_LOADS
     // The rest of the state is first needed by the controller: issued only now, behind the positions of EVERY wave
     // (all 4096 waves issue at once; issued up front, these 21 MB would be served before the last wave's position)
     __builtin_amdgcn_sched_barrier(0);
-    if (live) {
+    if (live && !late_loads) {
         q[0] = wb.quat[la]; q[1] = (wb.quat + T)[la]; q[2] = (wb.quat + 2 * T)[la]; q[3] = (wb.quat + 3 * T)[la];
         v[0] = wb.vel[la]; v[1] = (wb.vel + T)[la]; v[2] = (wb.vel + 2 * T)[la];
         w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la];
@@ -561,6 +582,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #else
     const bool ring = false;
 #endif
+    if (late_loads && live && !doit) { // a masked or NaN-action env keeps its state: loaded here for the outputs
+        q[0] = wb.quat[la]; q[1] = (wb.quat + T)[la]; q[2] = (wb.quat + 2 * T)[la]; q[3] = (wb.quat + 3 * T)[la];
+        v[0] = wb.vel[la]; v[1] = (wb.vel + T)[la]; v[2] = (wb.vel + 2 * T)[la];
+        w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la];
+    }
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
         // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane.
@@ -581,7 +607,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // env, so the whole wave is here.)
                 const int lane = tid & 63;
                 // tile + lane: neighbour (lane + k) mod 64 at offset k, no wrap; lane << 2 = ds_bpermute byte address of this lane
-                downwash_acc = downwash_ring64(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc);
+                downwash_acc = downwash_ring64(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
+                    if (!late_loads) return;
+                    // (the controller memory the outer loop of the cascade wants right after this loop was tried here too,
+                    // passes 10..14: no gain, 27.2 against 27.2 us per step, and spills in set_target_pos)
+                    switch (j) { // `doit` is uniform per env = per wave, so every lane here is live: la == tid
+                    case 0: q[0] = wb.quat[la]; break;
+                    case 1: q[1] = (wb.quat + T)[la]; break;
+                    case 2: q[2] = (wb.quat + 2 * T)[la]; break;
+                    case 3: q[3] = (wb.quat + 3 * T)[la]; break;
+                    case 4: v[0] = wb.vel[la]; break;
+                    case 5: v[1] = (wb.vel + T)[la]; break;
+                    case 6: v[2] = (wb.vel + 2 * T)[la]; break;
+                    case 7: w[0] = wb.angvel[la]; break;
+                    case 8: w[1] = (wb.angvel + T)[la]; break;
+                    case 9: w[2] = (wb.angvel + 2 * T)[la]; break;
+                    default: break;
+                    }
+                });
             } else
 #endif
             {
@@ -771,20 +814,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         int n = 0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) { n += wcnt[k]; wend[k] = n; }
-#if MRS_EARLY_TAIL
-        // A wave without a share of the solve would only wait at the barrier below: it finishes its free-flying lanes
-        // now (pose, state store, observation slice) and leaves their post-step position in the stash for the
-        // adjacency phase; only its grounded lanes are left for after the solve.
-        const bool early = n > 0 && (tid & ~63) >= n; // wave-uniform, recomputed after the solve (nothing kept live)
-        if (early) {
-            if (doit && !parked) {
-                integrate_pose(A.P, p, q, v, w);
-                store_state(wb, la, T, p, q, v, w);
-                if (A.b.obs && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
-                sp[tid] = p[0]; sp[BLOCK + tid] = p[1]; sp[2 * BLOCK + tid] = p[2];
-            }
-        }
-#endif
+        // (Round 2 experiment, removed: a wave without a share of the solve finishing its free-flying lanes -- pose, store,
+        // observation -- instead of waiting at the barrier below.  No gain, 28.0 against 27.9 us: it then runs the
+        // tail twice, once for the free-flying and once for the grounded lanes.)
         if (n > 0) { // uniform over the workgroup
             // The solving wave is the workgroup's critical path (three waves wait for it at the barrier below) but
             // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
@@ -826,15 +858,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
         v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
         w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
-#if MRS_EARLY_TAIL
-        const bool todo = doit && !((n > 0 && (tid & ~63) >= n) && !parked);
-        if (todo) {
-            integrate_pose(A.P, p, q, v, w);
-            store_state(wb, la, T, p, q, v, w);
-        }
-        TL(7); // pose + store
-        if (A.b.obs && live && A.n_obs > 0 && (todo || !doit)) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
-#else
+        // (the mirror image of MRS_LATE_LOADS -- the 13 state stores spread over the passes of the adjacency pair loop
+        // instead of one burst ahead of it -- was measured: no gain, 27.0 against 27.0 us per step)
         if (doit) {
             integrate_pose(A.P, p, q, v, w);
             store_state(wb, la, T, p, q, v, w);
@@ -843,7 +868,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         TL(7); // pose + store
         if (A.b.obs && live && A.n_obs > 0)
             write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
-#endif
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
         if (A.do_adj)

@@ -23,7 +23,15 @@ for T0 in (200, 800):
     for t in range(T0 if T0 == 200 else 600):
         sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
     torch.cuda.synchronize()
-    tl = sh.rpm.flatten()[:E * 16].view(E, 16).cpu().numpy()[:, :9]      # one wave per env at N=64
+    full = sh.rpm.flatten()[:E * 16].view(E, 16).cpu().numpy()
+    tl = full[:, :9]      # one wave per env at N=64
+    if full[:, 9].max() > 0:
+        print("  head of the kernel: arguments arrived + loads issued at %.0f [%.0f .. %.0f], positions staged at %.0f [%.0f .. %.0f]" % (
+            full[:, 9].mean(), full[:, 9].min(), full[:, 9].max(), full[:, 10].mean(), full[:, 10].min(), full[:, 10].max()))
+        st = full[:, 11].reshape(-1, 8)          # 8 waves per workgroup; workgroup w runs on XCD w % 8
+        for x in range(2):
+            s0 = st[x::8].ravel(); s0 = (s0 - s0.min()) % (1 << 24)
+            print("  wave start spread on XCD %d: median %.0f, 90%% %.0f, max %.0f ticks after the first" % (x, np.median(s0), np.percentile(s0, 90), s0.max()))
     print("after %d steps (clock64 ticks; mean over %d waves, [min..max] of the cumulative stamp)" % (T0, E))
     prev = np.zeros(E)
     for k, nm in enumerate(names):
