@@ -426,7 +426,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const long long t_start = clock64();
     float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
 #define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
-    if (tl && (tid & 63) == 0) tl[11] = (float)(t_start & 0xFFFFFF); // start of the wave on the (per-XCD) counter, for the launch stagger
+    if (tl && (tid & 63) == 0) tl[11] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF); // wave start on the 100 MHz chip-wide clock
 #elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/isa_sections.py)
 #define TL(k) asm volatile("; MRS_MARK " #k)
 #else
@@ -874,6 +874,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)AW,
                                          make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
         TL(8); // observation + adjacency
+#ifdef MRS_TIMELINE
+        if (tl && (tid & 63) == 0) tl[12] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF);
+#endif
         return;
     }
     // Two-level compaction into one global list: lanes take slots from an LDS counter, ONE lane per

@@ -28,10 +28,12 @@ for T0 in (200, 800):
     if full[:, 9].max() > 0:
         print("  head of the kernel: arguments arrived + loads issued at %.0f [%.0f .. %.0f], positions staged at %.0f [%.0f .. %.0f]" % (
             full[:, 9].mean(), full[:, 9].min(), full[:, 9].max(), full[:, 10].mean(), full[:, 10].min(), full[:, 10].max()))
-        st = full[:, 11].reshape(-1, 8)          # 8 waves per workgroup; workgroup w runs on XCD w % 8
-        for x in range(2):
-            s0 = st[x::8].ravel(); s0 = (s0 - s0.min()) % (1 << 24)
-            print("  wave start spread on XCD %d: median %.0f, 90%% %.0f, max %.0f ticks after the first" % (x, np.median(s0), np.percentile(s0, 90), s0.max()))
+        t0, t1 = full[:, 11], full[:, 12]          # 10 ns ticks, 20 bits: one launch fits without a wrap almost always
+        if t1.max() - t0.min() < 1e4:
+            first = t0.min()
+            print("  wave starts after the first wave's: median %.2f us, 90%% %.2f us, last %.2f us; wave ends: first %.2f us, median %.2f us, last %.2f us" % (
+                np.median(t0 - first) / 100, np.percentile(t0 - first, 90) / 100, (t0.max() - first) / 100,
+                (t1.min() - first) / 100, np.median(t1 - first) / 100, (t1.max() - first) / 100))
     print("after %d steps (clock64 ticks; mean over %d waves, [min..max] of the cumulative stamp)" % (T0, E))
     prev = np.zeros(E)
     for k, nm in enumerate(names):
