@@ -110,7 +110,8 @@ def main():
     def make_env(a_format):
         env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
                               RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos),
-                              A_FORMAT=a_format, ENV_INDEX_BASE=base, DEVICE=str(dev), CHECK_NAN="lazy")
+                              A_FORMAT=a_format, ENV_INDEX_BASE=base, DEVICE=str(dev), CHECK_NAN="lazy",
+                              HISTORY_SLOTS=int(os.environ.get("MRS_BENCH_HISTORY_SLOTS", "0")))
         env.reset(ori=torch.from_numpy(eul))
         return env
 
@@ -118,18 +119,22 @@ def main():
     total = args.warmup + args.steps
     n_regions = 2 if (world > 1 or not args.no_dense_a) else 1
     table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range((args.rollin + n_regions * total) // 50 + 2)]
-    # Process/device warm-up on a SCRATCH swarm, before anything measured: the first ~0.1 s of launches of a fresh
-    # process run ~20 % slow (62 vs 52 us/step measured; clock ramp + the HIP runtime growing its signal/kernarg
-    # pools), and on a fresh box the first process is slower still.
+    # Device warm-up on a SCRATCH swarm, run immediately before every measured swarm starts (its roll-in follows with no
+    # host-side gap): after the GPU has been idle for tens of milliseconds -- process start, but also the allocations
+    # and the reset of a new env -- this GPU runs the next 30-50 ms of kernels up to 20 % slow (rocprofv3 kernel
+    # durations 26.7 us before a 52 ms gap, 29 -> 33 us over the following 100 launches, back to 26.5 after ~1000), and
+    # the first process on a fresh box more so.  The measured swarm is created BEFORE its warm-up for that reason.
     prewarm_s = float(os.environ.get("MRS_BENCH_PREWARM_S", "1.0"))
-    if prewarm_s > 0:
-        scratch = make_env("packed")
-        t_end = time.perf_counter() + prewarm_s
+    scratch = make_env("packed") if prewarm_s > 0 else None
+
+    def warm(seconds):
+        if scratch is None:
+            return
+        t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
             for t in range(500):
                 scratch.step(table[0])
             torch.cuda.synchronize()
-        del scratch
     gather = mdist.ObsAllGather(E, N, 6, dev) if world > 1 else None
     # HIP events on the stream the step kernels are launched on (torch's current stream) bracket SPANS of
     # EV_SPAN consecutive mrs_step launches, one span every EV_EVERY steps: on this stack a timing-event pair
@@ -139,11 +144,14 @@ def main():
     EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "10")), EV_EVERY, args.steps))
 
     def rollin(env):
-        """ROLLIN untimed steps from the spawn state: the workload's steady state (a part of the swarm grounded)."""
+        """ROLLIN untimed steps from the spawn state: the workload's steady state (a part of the swarm grounded).
+        Returns the grounded share as a DEVICE scalar, read after the timed region: no host wait between roll-in and
+        warm-up.  (After an idle gap of tens of milliseconds this GPU runs the next ~30 ms of kernels 10-20 % slow --
+        rocprofv3 kernel durations 27 -> 33 us across such a gap, decaying over ~1000 launches; the timed steps would
+        be measuring that ramp.)"""
         for t in range(args.rollin):
             env.step(table[t // 50])
-        torch.cuda.synchronize()
-        return float((env.shard.pos[2] < 0.6).float().mean())
+        return (env.shard.pos[2] < 0.6).float().mean()
 
     def timed_region(env, t_first, with_gather):
         """W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier; max over ranks."""
@@ -153,16 +161,14 @@ def main():
             env.step(table[t // 50])
             if with_gather:
                 gather.gather(env._Xring.newest())
+        # everything the timed loop needs exists before the warm-up, so that nothing but the barrier + synchronize
+        # stands between the last warm-up step and the first timed one
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(max(1, (args.steps - EV_SPAN) // EV_EVERY + 1))]
         for t in range(t_first, t_first + args.warmup):
             one_step(t)
         if with_gather:
             gather.wait()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(max(1, (args.steps - EV_SPAN) // EV_EVERY + 1))]
 
         def timed_step(*a, **k):
             i = timed_step.i
@@ -174,6 +180,11 @@ def main():
             if j < len(ev) and r == EV_SPAN - 1:
                 ev[j][1].record()
         timed_step.i = 0
+        if not os.environ.get("MRS_BENCH_DEBUG_NOSYNC"):   # diagnostic only: the contract requires this synchronize
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
         env.shard.step_ptr = timed_step
         t0 = time.perf_counter()
         for t in range(t_first + args.warmup, t_first + total):
@@ -189,6 +200,8 @@ def main():
         env.shard.step_ptr = shard_step
         env.check_errors()
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / EV_SPAN
+        if os.environ.get("MRS_BENCH_DEBUG_SPANS"):   # diagnostic: the sampled spans in order (us per launch)
+            print("spans:", " ".join("%.1f" % (a.elapsed_time(b) / EV_SPAN * 1e3) for a, b in ev), file=sys.stderr, flush=True)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -197,6 +210,10 @@ def main():
 
     env = make_env("dense" if args.dense_a else "packed")
     assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
+    # the torch kernels of rollin()'s grounded-share expression are loaded here, not at their first use between roll-in and
+    # warm-up (a code-object load is ~55 ms of host time with the GPU idle: kernel trace, tools/trace_bench.sh)
+    float((env.shard.pos[2] < 0.6).float().mean())
+    warm(prewarm_s)
     grounded = rollin(env)
     agent_steps = float(E) * N * args.steps * world
     extra = {}
@@ -207,6 +224,7 @@ def main():
             # the reference's return format: float32 0/1 (E,K+1,N,N) adjacency materialised every step (a second launch)
             del env
             denv = make_env("dense")
+            warm(min(prewarm_s, 0.3))
             rollin(denv)
             d_elapsed, _, _ = timed_region(denv, args.rollin, False)
             extra["dense_a"] = {"value": agent_steps / d_elapsed, "unit": "agent-steps/s", "ms_per_step": d_elapsed / args.steps * 1e3,
@@ -243,7 +261,7 @@ def main():
     out = {
         "metric": "agent-steps/sec (whole node) at N_AGENTS=64 x4096 envs", "value": value, "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rollin_steps": args.rollin,
-        "grounded_fraction_after_rollin": grounded, "ms_per_step": elapsed / args.steps * 1e3,
+        "grounded_fraction_after_rollin": float(grounded), "ms_per_step": elapsed / args.steps * 1e3,
         "host_ms_per_step": host_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "N_AGENTS=64 x %d envs/GPU, ACTION_TYPE=set_target_vel (PID), RETURN_A=True COMM_RANGE=5.0, "

@@ -620,6 +620,9 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
 #ifndef MRS_CONTACT_TOL
 #define MRS_CONTACT_TOL 1e-7f
 #endif
+#ifndef MRS_CONTACT_RELTOL
+#define MRS_CONTACT_RELTOL 1
+#endif
 struct F3 {
     float x, y, z;
 };
@@ -742,7 +745,14 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 #ifdef MRS_TIMELINE // diagnostic: per lane, the first even sweep count at which it had converged
         if (diag && diag[0] == 0.f && moved <= tol) diag[0] = (float)(it + 2);
 #endif
+#if MRS_CONTACT_RELTOL
+        // ... of the resting impulse or of the largest impulse of this body, whichever is larger: a touchdown's impulses are
+        // ~100 resting ones, and float32 sweeps cannot move them by less than 6e-8 of themselves -- measured against the
+        // resting impulse alone such a body never "converges" and keeps its whole wave in the loop for all the sweeps
+        if (moved <= fmaxf(tol, MRS_CONTACT_TOL * fmaxf(fmaxf(ln[0], ln[1]), fmaxf(ln[2], ln[3])))) break;
+#else
         if (moved <= tol) break;
+#endif
     }
 #ifdef MRS_TIMELINE
     if (diag) diag[1] = (float)(it + 2 < P.solver_iters ? it + 2 : P.solver_iters);

@@ -19,7 +19,13 @@ import torch
 class HistoryRing:
     def __init__(self, k_hops, slice_shape, dtype, device, slots=0, pad="copy", view_fn=None):
         self.K = int(k_hops)
-        self.L = max(int(slots) if slots else 8 * (self.K + 1), 2 * (self.K + 1))
+        if not slots:
+            # default length 16 windows: the K surviving slices move once per L-K steps, a device copy queued between two
+            # step kernels (8 windows cost the bench loop 0.8 us per step with the copy staged through a clone, 16 without
+            # the clone 0.2 us; much longer rings -- 1 GiB was tried -- stalled the first process on a fresh box for ~50 ms
+            # at a wrap inside the timed region, twice out of twice)
+            slots = 16 * (self.K + 1)
+        self.L = max(int(slots), 2 * (self.K + 1))
         self.pad = pad
         self.buf = torch.zeros((self.L,) + tuple(slice_shape), dtype=dtype, device=device)
         self._base = self.buf.data_ptr()
@@ -41,7 +47,7 @@ class HistoryRing:
             if self.head == 0:
                 new_head = self.L - (self.K + 1)
                 if self.K > 0:
-                    self.buf[new_head + 1:new_head + 1 + self.K].copy_(self.buf[0:self.K].clone())
+                    self.buf[new_head + 1:new_head + 1 + self.K].copy_(self.buf[0:self.K])   # L >= 2(K+1): no overlap
                 self.head = new_head
             else:
                 self.head -= 1

@@ -76,7 +76,7 @@ class MRS(_EnvBase):
         self.ENV_INDEX_BASE = 0       # global index of this shard's first env (multi-GPU)
         self.RESET_CONTROLLERS = False  # reference: PID integrators survive reset() (QuadControl objects persist)
         self.CHECK_NAN = None         # "sync" | "lazy" | "off"; None = sync for N_ENVS==1 else lazy
-        self.HISTORY_SLOTS = 0        # ring length; 0 = 8*(K_HOPS+1)
+        self.HISTORY_SLOTS = 0        # ring length; 0 = 16*(K_HOPS+1)
         self.COPY_OUTPUTS = None      # None = clone returned stacks iff N_ENVS == 1 (reference returns fresh tensors)
         self.AUTO_RESET = False       # vectorised loops: envs whose `done` is set are reset inside step() (reset_envs)
         # BulletSim constants (BulletSim.py:11-15); DT/GRAVITY reach the world only, never the controller

@@ -1,0 +1,51 @@
+"""Diagnostic: per-100-step kernel time of the bench workload through env.step() (history rings, rotating output slots)
+and through SwarmShard.step_ptr with fixed output buffers, same spawn and action stream."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np, torch, mrsgym_amd
+from mrsgym_amd.native import ACT
+from util_scenarios import ActionStream, grid_spawn
+E, N, STEPS = 4096, 64, 1800
+pos, eul = grid_spawn(E, N)
+acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
+table = [torch.from_numpy(acts(50 * k)).cuda() for k in range(STEPS // 50 + 2)]
+
+
+def state_fn(quad):
+    return torch.cat([quad.get_pos(), quad.get_vel()])
+
+
+NOSYNC = os.environ.get("NOSYNC") == "1"   # 1: the host never waits inside the run (like bench.py's timed region)
+
+
+def blocks(step):
+    evs = []
+    for b in range(STEPS // 100):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in range(b * 100, b * 100 + 100):
+            step(t)
+        e1.record()
+        if not NOSYNC:
+            torch.cuda.synchronize()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 10 for a, b in evs]
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "both"
+if which in ("both", "shard"):
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torch.int64, device="cuda")
+    r = blocks(lambda t: sh.step_ptr(table[t // 50], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0))
+    print("shard.step_ptr :", " ".join("%.1f" % x for x in r), " grounded %.3f" % float((sh.pos[2] < 0.6).float().mean()), flush=True)
+if which in ("both", "env"):
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=3, COMM_RANGE=5.0, RETURN_A=True,
+                          ACTION_TYPE="set_target_vel", HEADLESS=True, START_POS=torch.from_numpy(pos), A_FORMAT="packed",
+                          DEVICE="cuda:0", CHECK_NAN="lazy")
+    env.reset(ori=torch.from_numpy(eul))
+    r = blocks(lambda t: env.step(table[t // 50]))
+    print("env.step       :", " ".join("%.1f" % x for x in r), " grounded %.3f" % float((env.shard.pos[2] < 0.6).float().mean()), flush=True)
