@@ -571,3 +571,27 @@ def test_bench_contract_single_and_two_ranks():
     assert "all-gather" in d2["config"]["parallelism"]
     assert d2["no_exchange"]["value"] > 0 and d2["obs_allgather"]["bytes_sent_per_rank_per_step"] == 64 * 64 * 6 * 4
     assert d2["obs_allgather"]["xgmi_floor_ms"] > 0
+
+
+def test_handle_on_a_device_that_is_not_the_current_one():
+    """a handle is bound to its device; every launching entry point selects it for the call (DeviceGuard in
+    mrs_kernels.hip) whatever torch's current device is.  Needs two GPUs: skipped on the one-GPU box."""
+    import torch, mrsgym_amd
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    torch.cuda.set_device(0)
+    E, N = 4, 12
+    pos, eul = grid_spawn(E, N)
+    z = np.zeros((E, N, 3), np.float32)
+    out = []
+    for dev in ("cuda:0", "cuda:1"):
+        sh = mrsgym_amd.SwarmShard(E, N, dev)
+        sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+        a = torch.from_numpy(ActionStream("set_target_vel", E, N, pos, seed=3)(0)).to(dev)
+        obs = torch.zeros(E, N, sh.D, device=dev)
+        for _ in range(5):
+            with torch.cuda.device(0):        # the current device stays 0 throughout
+                sh.step(a, "set_target_vel", obs_out=obs)
+        torch.cuda.synchronize(dev)
+        out.append(obs.cpu().numpy())
+    np.testing.assert_array_equal(out[0], out[1])
