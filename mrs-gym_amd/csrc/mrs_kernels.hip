@@ -9,6 +9,7 @@
 // state planes once in and once out per step.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1352,7 +1353,10 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     // 64 threads 32.1, 128: 30.5, 256: 29.0, 512: 27.5, 1024: 29.6 -- two workgroups of eight waves per CU pool their
     // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
     h->sblock = (n_agents == 64) ? 512 : 256;
-    if (const char *sb = getenv("MRS_STEP_BLOCK")) { const int v = atoi(sb); if (n_agents == 64 && (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024)) h->sblock = v; }
+    if (const char *sb = getenv("MRS_STEP_BLOCK")) {
+        const int v = atoi(sb);
+        if ((v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) && v >= n_agents && n_agents <= 256) h->sblock = v;
+    }
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
@@ -1451,7 +1455,7 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
 #endif
     if (fused && h->sblock != 256) { // N = 64 with fewer envs (waves) per workgroup: same kernel, smaller hand-off group
         StepArgs B = A;
-        B.epb = h->sblock / 64;
+        B.epb = std::min(h->sblock / h->N, 256); // whole envs per workgroup (the NaN-flag array holds 256)
         const int g = (h->E + B.epb - 1) / B.epb;
         const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + (size_t)(h->sblock / 64) * sizeof(int);
         if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true>), dim3(g), dim3(128), l, st, B);
