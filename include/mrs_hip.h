@@ -78,7 +78,11 @@ typedef struct MrsParams {
     int32_t enable_contact;
     double ground_z, friction, erp, contact_threshold;
     int32_t solver_iters;
-    int32_t reserved0;
+    /* 1: the attitude controller rebuilds its rotation matrix from the FLOAT32-rounded Euler angles exactly as
+     * from_euler(get_ori()) does (Object.py:97 -> QuadControl.py:99); 0 (default): from the unrounded angles of the same
+     * float32 quaternion read-back -- they differ by <= 2^-24 relative per angle, the reference's own read-back noise
+     * (deviation 7); saves ~130 float64 instructions per agent-step. */
+    int32_t round_euler_readback;
 } MrsParams;
 
 /* Device buffers of one swarm shard (all borrowed).  Optional members may be NULL. */

@@ -287,18 +287,16 @@ MRS_DEV void rot_small(double s, double c, double d, double &so, double &co)
     so = __builtin_fma(c, d, s) - s * t;
     co = __builtin_fma(-s, d, c) - c * t;
 }
-#ifndef MRS_FAST_RE
-#define MRS_FAST_RE 0
-#endif
 // `carried`: the three float64 angles of exactly this float32 quaternion, evaluated by the previous step's observation
 // slice (observe<true, .>) -- wave-uniform pointer or null.
-MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re, const double *carried = nullptr)
+// `rounded` (MrsParams.round_euler_readback, uniform over the launch): false takes Re = R, see below.
+MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re, bool rounded, const double *carried = nullptr)
 {
     o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
     o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
     o.wx = (float)w[0]; o.wy = (float)w[1]; o.wz = (float)w[2];
     const M3 R = quat_to_matrix_scipy((double)(float)q[0], (double)(float)q[1], (double)(float)q[2], (double)(float)q[3]);
-#if MRS_FAST_RE
+    if (!rounded) {
     // Re := R.  from_euler(fl32(as_euler(R))) differs from R by the float32 rounding of the three angles
     // (<= 2^-24 |angle|, i.e. <= 2e-7 on the matrix elements): the reference's own read-back noise, not signal.
     // Only the ground-effect switch looks at the angles themselves (Quadcopter.py:80): roll < pi/2 and pitch < pi/2
@@ -312,7 +310,7 @@ MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3
     const bool pitch_ok = !((R.m21 * R.m21 + R.m22 * R.m22) < 4.8e-16 && R.m20 < 0.0);
     o.roll = roll_ok ? 0.f : 2.f; o.pitch = pitch_ok ? 0.f : 2.f; o.yaw = 0.f; // only compared with pi/2 downstream
     return;
-#endif
+    }
     const double h = sqrt64(R.m21 * R.m21 + R.m22 * R.m22);
     double r, pt, y;
     if (carried) { r = carried[0]; pt = carried[1]; y = carried[2]; }

@@ -683,7 +683,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     const bool stale = live && !(ekey.x == (float)q[0] && ekey.y == (float)q[1] && ekey.z == (float)q[2] && ekey.w == (float)q[3]);
                     have_eul = __builtin_amdgcn_ballot_w64(stale) == 0;
                 }
-                if (have_eul) observe_ctrl(p, q, v, w, ob, R, eang); else observe_ctrl(p, q, v, w, ob, R);
+                const bool rounded = A.P.round_euler_readback != 0;
+                if (have_eul) observe_ctrl(p, q, v, w, ob, R, rounded, eang); else observe_ctrl(p, q, v, w, ob, R, rounded);
             } else observe<true, true>(p, q, v, w, ob);
             TL(21); // read-back + rotation matrices
             if (NEEDS_PID) {

@@ -47,7 +47,7 @@ class MrsParams(C.Structure):
         ("lin_damp", C.c_double), ("ang_damp", C.c_double), ("max_coord_vel", C.c_double),
         ("use_gyro", C.c_int32), ("enable_contact", C.c_int32),
         ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("contact_threshold", C.c_double),
-        ("solver_iters", C.c_int32), ("reserved0", C.c_int32),
+        ("solver_iters", C.c_int32), ("round_euler_readback", C.c_int32),
     ]
 
 
