@@ -261,6 +261,8 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
             if (!comm_inf) {
                 const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
+                // (consuming the handed-over verdicts one pass late, as the downwash loop does with its terms, was measured:
+                // no gain, 26.3 against 26.3 us per step)
                 auto verdict = [&](int k, float d2) {
                     const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
                     lo |= bit;
