@@ -400,6 +400,9 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 #define MRS_P_TAIL 0
 #define MRS_P_ADJ 0
 #endif
+#ifndef MRS_P_SOLVE
+#define MRS_P_SOLVE 3
+#endif
 #ifndef MRS_FUSED_WAVES
 // the fused kernels are held to 128 VGPRs = 4 resident waves per SIMD = all 1024 workgroups of the bench swarm
 // resident at once (set_target_vel / _pos would take 132 / 134 uncapped and drop to 3: measured 43.2 vs 37.5 us)
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
             // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
             // priority lets it issue whenever it is ready.
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(MRS_P_SOLVE);
             if (const int sl = tid; sl < n) { // n <= BLOCK: every lane lists at most itself
                 int seg = 0;
 #pragma unroll
