@@ -1358,7 +1358,17 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     // N = 64: eight envs (waves) per workgroup.  Measured at the bench size (tools/abl_sblock.sh, same build, us per step):
     // 64 threads 32.1, 128: 30.5, 256: 29.0, 512: 27.5, 1024: 29.6 -- two workgroups of eight waves per CU pool their
     // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
-    h->sblock = (n_agents == 64) ? 512 : 256;
+    // ... as long as that still gives every CU a workgroup: a swarm of fewer than 8 x CUs envs takes the largest workgroup
+    // that does (1024 envs on 256 CUs: 256 threads 13.9 us per step, 512: 17.5; 512 envs: 128 threads 13.7, 512: 16.0)
+    h->sblock = 256;
+    if (n_agents == 64) {
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        h->sblock = 64;
+        for (int sb = 512; sb >= 128; sb >>= 1)
+            if ((n_envs + sb / 64 - 1) / (sb / 64) >= ncu) { h->sblock = sb; break; }
+    }
     if (const char *sb = getenv("MRS_STEP_BLOCK")) {
         const int v = atoi(sb);
         if ((v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) && v >= n_agents && n_agents <= 256) h->sblock = v;
