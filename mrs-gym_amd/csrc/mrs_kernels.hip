@@ -161,22 +161,65 @@ __device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const dou
     write_obs(A.obs_code, A.n_obs, o, p, q, v, w, eul_key, eul_ang, (size_t)A.T);
 }
 
+// two float32 in an aligned register pair: the operand form of the packed instructions (v_pk_add/mul/fma_f32: two IEEE
+// operations for the issue cost of one, tools/micro/valu_rates2.hip)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
+
 // bit-packed adjacency row of agent i from the env's LDS position tile (MRS.calc_A, MRS.py:117-124):
 // float32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it, sqrt(d2) <= R
 // folded into d2 <= d2_thresh (largest float whose correctly rounded sqrt is <= R; host-computed).
-__device__ __forceinline__ void adjacency_row(const StepArgs &A, const float4 *tile_env, int i, float4 me, uint64_t *row)
+// The tile is three arrays (tx, ty, tz = the env's first agent): one ds_read2_b32 -- a broadcast, every lane of the
+// env reads the same j -- puts agents j and j+1 into a register pair, the differences and the squared distance of
+// both come from five packed instructions, and each verdict lands at a compile-time bit position (one select and one
+// OR; the row's own bit is cleared once at the end).  Was: one float4 read, six scalar operations, two compares and a
+// 64-bit variable shift per agent -- 13 vector instructions per pair against 6 (N = 256: 68 -> see DESIGN.md section 6).
+__device__ __forceinline__ void adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row)
 {
+    float thr = thr_s;
+    asm volatile("" : "+v"(thr)); // not re-read from the argument segment inside the loop (see adjacency_phase)
+    const bool inf = A.comm_inf != 0;
+    const f2 mx = splat(me.x), my = splat(me.y), mz = splat(me.z);
     for (int wd = 0; wd < A.W; ++wd) {
-        uint64_t bits = 0;
-        const int jn = min(64, A.N - wd * 64);
-        for (int jj = 0; jj < jn; ++jj) {
-            const int j = wd * 64 + jj;
-            const float4 pj = tile_env[j];
-            const float dx = f32sub(me.x, pj.x), dy = f32sub(me.y, pj.y), dz = f32sub(me.z, pj.z);
-            const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
-            const bool adj = (A.comm_inf ? true : (d2 <= A.d2_thresh)) && (j != i);
-            bits |= (uint64_t)adj << jj;
+        const int j0 = wd * 64, jn = min(64, A.N - j0);
+        uint32_t half[2] = {0u, 0u};
+        if (inf) {
+            const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
+            half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
+        } else if (jn == 64) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int jj = 0; jj < 32; jj += 2) {
+                    const int j = j0 + hh * 32 + jj;
+                    const f2 dx = pk_sub(mx, f2{tx[j], tx[j + 1]}), dy = pk_sub(my, f2{ty[j], ty[j + 1]}), dz = pk_sub(mz, f2{tz[j], tz[j + 1]});
+                    const f2 d2 = pk_fma(dz, dz, pk_fma(dy, dy, pk_mul(dx, dx)));
+                    bits |= (d2.x <= thr ? (1u << jj) : 0u) | (d2.y <= thr ? (2u << jj) : 0u);
+                }
+                half[hh] = bits;
+            }
+        } else { // the last, partial word of an N that is not a multiple of 64
+            for (int jj = 0; jj < jn; ++jj) {
+                const int j = j0 + jj;
+                const float dx = f32sub(me.x, tx[j]), dy = f32sub(me.y, ty[j]), dz = f32sub(me.z, tz[j]);
+                const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
+                if (d2 <= thr) half[jj >> 5] |= 1u << (jj & 31);
+            }
         }
+        uint64_t bits = ((uint64_t)half[1] << 32) | half[0];
+        if ((unsigned)(i - j0) < 64u) bits &= ~(1ull << (i - j0)); // ones - eye (MRS.py:118-119, :123)
         row[wd] = bits;
     }
 }
@@ -199,19 +242,6 @@ __device__ __forceinline__ void wave_lds_sync()
 // ds_read2_b32 puts the coordinates of neighbours k and k+1 into an aligned register pair -- the operand form of the
 // packed float32 instructions (v_pk_add/mul/fma_f32: two IEEE operations for the issue cost of one, measured in
 // tools/micro/valu_rates2.hip), which the pair loops below use for everything that is not a transcendental or a compare.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 pk_mul(f2 a, f2 b)
-{
-#pragma clang fp contract(off)
-    return a * b;
-}
-__device__ __forceinline__ f2 pk_sub(f2 a, f2 b)
-{
-#pragma clang fp contract(off)
-    return a - b;
-}
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
 __device__ __forceinline__ float *tile64(float4 *lds_tile, int el) { return reinterpret_cast<float *>(lds_tile + el * 128); }
 __device__ __forceinline__ void tile64_write(float4 *lds_tile, int el, int i, float x, float y, float z)
 {
@@ -231,8 +261,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                                                 uint64_t *row, float4 mine)
 {
     const bool n64 = (NFIX == 64 || A.N == 64);
+    float *const gx = reinterpret_cast<float *>(lds_tile); // any other N: three arrays of BLOCK floats (see adjacency_row)
     if (n64) tile64_write(lds_tile, el, i, mine.x, mine.y, mine.z);
-    else lds_tile[tid] = mine;
+    else { gx[tid] = mine.x; gx[BLOCK + tid] = mine.y; gx[2 * BLOCK + tid] = mine.z; }
     if (n64) wave_lds_sync(); else __syncthreads();
     if (n64) {
         // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
@@ -289,7 +320,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
         }
     } else if (live) {
-        adjacency_row(A, lds_tile + el * A.N, i, lds_tile[tid], row);
+        adjacency_row(A, thr_s, gx + el * A.N, gx + BLOCK + el * A.N, gx + 2 * BLOCK + el * A.N, i, mine, row);
     }
 }
 
