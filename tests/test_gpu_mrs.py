@@ -206,6 +206,26 @@ def test_lazy_nan_action_is_raised_even_with_short_episodes():
     env.check_errors()
 
 
+def test_lazy_nan_poll_never_blocks_and_still_raises():
+    """No reset in the loop: the in-loop poll (every 256 steps) copies the flag word to pinned memory without waiting and
+    looks at it one poll later, so the exception surfaces within three poll periods."""
+    import mrsgym_amd
+    E, N = 4, 6
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, SEED=5, MAX_TIMESTEPS=10**9)
+    a = torch.zeros(E, N, 3, device="cuda")
+    raised_at = None
+    try:
+        for t in range(800):
+            act = a.clone()
+            if t == 3:
+                act[1, 0, 2] = float("nan")
+            env.step(act)
+    except Exception as exc:
+        raised_at = t
+        assert "NaN" in str(exc) and "[1]" in str(exc)
+    assert raised_at is not None and raised_at <= 767
+
+
 def test_generic_state_fn_is_vmapped_across_envs():
     """A state_fn the recogniser cannot fuse (arithmetic on the getters, per-agent data), N_ENVS > 1: evaluated for all
     E*N quadcopters at once with torch.func.vmap -- same numbers as the per-agent formula on the batched getters."""
