@@ -447,3 +447,35 @@ def test_awkward_swarm_sizes_match_oracle(N):
         assert float(sh.pos[2].min()) < 0.58, "the run was meant to reach the contact zone"
         sh.adjacency_expand(adj, dense)
         assert np.array_equal(dense.cpu().numpy(), sw.adjacency(2.0)), atype
+
+
+@pytest.mark.parametrize("atype", ["set_target_vel", "set_speeds"])
+def test_workgroup_size_does_not_change_results(atype):
+    """N = 64: the step's workgroup holds 1, 2, 4 or 8 envs depending on the swarm size (mrs_create) -- eight pool their
+    grounded bodies into shared solver waves through LDS, one keeps everything in its own wave.  Same physics: 400 steps
+    through touchdown with 8-env and with 1-env workgroups must leave bitwise identical states, observations and rows."""
+    import mrsgym_amd
+    E, N = 21, 64               # not a multiple of 8: the last workgroup of the 512-thread form is partly empty
+    pos, eul = grid_spawn(E, N, seed=4)
+    z = np.zeros((E, N, 3), np.float32)
+    stream = ActionStream(atype, E, N, pos, seed=21)
+    table = [torch.from_numpy(stream(t)).cuda() for t in range(400)]   # the same actions for both runs
+    out = {}
+    old = os.environ.get("MRS_STEP_BLOCK")
+    try:
+        for blk in ("64", "512"):
+            os.environ["MRS_STEP_BLOCK"] = blk          # read by mrs_create
+            sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+            sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+            obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+            for t in range(400):
+                sh.step(table[t], atype, obs_out=obs, adj_out=adj, comm_range=3.0)
+            out[blk] = [getattr(sh, k).clone() for k in ("pos", "quat", "vel", "angvel")] + [obs.clone(), adj.clone()]
+            assert float((sh.pos[2] < 0.6).float().mean()) > 0.05     # bodies did reach the ground
+    finally:
+        if old is None:
+            os.environ.pop("MRS_STEP_BLOCK", None)
+        else:
+            os.environ["MRS_STEP_BLOCK"] = old
+    for a, b in zip(out["64"], out["512"]):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
