@@ -695,6 +695,23 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     }
     float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwz = 0.f;
     F2 dwxy = {0.f, 0.f};
+    // Start of the sweeps (the oracle's contact_solve does the same): every active point carries the equal share of the
+    // impulse that stops the mean closing velocity, l0 = m max(sum rhs, 0) / n^2 -- exact for a body lying flat, which
+    // then needs no iteration; the sweeps correct it for everything else.  From a cold start 90 % of the grounded
+    // bodies needed 8-10 sweeps, with this start 86 % are done after the first pair (tools/sweeps_probe.py).
+    {
+        float nact = 0.f, rsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const bool a = Kn[k] != 0.f; nact += a ? 1.f : 0.f; rsum += a ? rhs[k] : 0.f; }
+        const float l0 = nact > 0.f ? fmaxf(rsum, 0.f) / (nact * nact * im) : 0.f; // m * mean(rhs) / n
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float l = Kn[k] != 0.f ? l0 : 0.f;
+            ln[k] = l;
+            dvz = __builtin_fmaf(l, im, dvz);
+            dwxy = __builtin_elementwise_fma(anxy[k], F2{l, l}, dwxy); dwz = __builtin_fmaf(anz[k], l, dwz);
+        }
+    }
     // the sweeps gain ~1.5 digits each (measured on the oracle); a lane stops once a whole sweep moved no
     // impulse by more than 1e-7 of the resting impulse m g dt -- float32 cannot resolve less anyway --
     // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle).
