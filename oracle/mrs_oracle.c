@@ -592,9 +592,10 @@ static void contact_solve(const OrcParams *p, const double pos[3], const double 
         }
     }
     /* The sweeps stop once a pair of sweeps has moved no impulse by more than 1e-7 of the resting impulse m g dt, or of
-     * the body's largest normal impulse (looked at after every second sweep, at most solver_iters sweeps). */
+     * the body's largest normal impulse, or has stopped making progress (looked at after every second sweep, at most
+     * solver_iters sweeps). */
     const double tol = 1e-7 * (p->mass * p->gravity * p->dt) + 1e-30;
-    double moved = 0;
+    double moved = 0, prev_moved = 3.0e38;
     for (int it = 0; it < p->solver_iters; ++it) {
         if ((it & 1) == 0) moved = 0;
         const int track = (it & 1);
@@ -639,6 +640,10 @@ static void contact_solve(const OrcParams *p, const double pos[3], const double 
             for (int k = 0; k < 8; ++k) if (active[k] && lam_n[k] > lmax) lmax = lam_n[k];
             const double t2 = 1e-7 * lmax;
             if (moved <= (tol > t2 ? tol : t2)) break;
+            /* ... or once a pair of sweeps has moved the impulses by at least half of what the pair before it did (no
+             * progress: the clamps of the friction pyramid chatter for a few per cent of the grounded bodies) */
+            if (moved >= 0.5 * prev_moved) break;
+            prev_moved = moved;
         }
     }
 }
