@@ -617,3 +617,23 @@ def test_handle_on_a_device_that_is_not_the_current_one():
         torch.cuda.synchronize(dev)
         out.append(obs.cpu().numpy())
     np.testing.assert_array_equal(out[0], out[1])
+
+
+def test_round_euler_readback_kwarg_reaches_the_kernel():
+    """MRS(..., ROUND_EULER_READBACK=True) selects the attitude controller's literal float32 rounding of the Euler
+    read-back (include/mrs_hip.h, DESIGN.md section 4 deviation 7): the flag arrives in the shard's parameters, and one
+    step of the two forms differs by what that rounding is worth -- more than nothing, less than 1e-6 rad/s."""
+    import mrsgym_amd
+    E, N = 3, 12
+    pos, eul = grid_spawn(E, N, seed=2, yaw_range=0.8)
+    a = torch.from_numpy(ActionStream("set_target_vel", E, N, pos, seed=9, coherent=True)(0)).cuda()
+    w = {}
+    for flag in (False, True):
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, START_POS=torch.from_numpy(pos),
+                              ACTION_TYPE="set_target_vel", ROUND_EULER_READBACK=flag)
+        assert int(env.shard.params.round_euler_readback) == int(flag)
+        env.reset(ori=torch.from_numpy(eul))
+        env.step(a)
+        w[flag] = env.shard.view(env.shard.angvel).clone()
+    d = float((w[True] - w[False]).abs().max())
+    assert 0.0 < d < 1e-6, d
