@@ -228,13 +228,21 @@ def test_nan_action_skips_env_and_flags_it():
     sh, sw, pos0 = _mk(E, N, "set_target_vel")
     a = np.zeros((E, N, 3), np.float32)
     a[2, 17, 1] = np.nan
+    for _ in range(3):                                           # a few steps first: non-trivial velocities
+        sh.step(torch.zeros(E, N, 3, device="cuda:0"), "set_target_vel")
     before = _gpu_state(sh)
-    sh.step(torch.from_numpy(a).cuda(), "set_target_vel")
+    obs = torch.zeros(E, N, sh.D, device="cuda:0")
+    sh.step(torch.from_numpy(a).cuda(), "set_target_vel", obs_out=obs)
     after = _gpu_state(sh)
     st = sh.status.cpu().numpy()
     assert list(st) == [0, 0, 1, 0]                              # MRS.py:247-248 -> raised lazily by the host
-    assert np.array_equal(after["pos"][2], before["pos"][2])     # that env did not step
+    for k in ("pos", "quat", "vel", "angvel"):                   # that env did not step: every state word as it was
+        assert np.array_equal(after[k][2], before[k][2]), k
     assert not np.array_equal(after["pos"][1], before["pos"][1])
+    o = obs.cpu().numpy()                                        # ... and its observation slice is that unchanged state
+    np.testing.assert_array_equal(o[2, :, :3], before["pos"][2].astype(np.float32))
+    np.testing.assert_array_equal(o[2, :, 3:6], before["vel"][2].astype(np.float32))
+    np.testing.assert_array_equal(o[1, :, :3], after["pos"][1].astype(np.float32))
 
 
 def test_unknown_action_type_raises_attribute_error():
