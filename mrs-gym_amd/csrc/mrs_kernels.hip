@@ -324,6 +324,17 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
     }
 }
 
+// |pair term| for two neighbours at once: d2 = dxy^2, rz = dz of both.  |dz| enters only through the abs operand modifier
+// of v_rcp_f32 / v_fma_f32 (the packed forms have none); operation for operation the arithmetic of downwash_mag2.
+__device__ __forceinline__ f2 downwash_mag2_pk(f2 d2, f2 rz, const DownwashRegs &dr)
+{
+    const f2 rdz = {__builtin_amdgcn_rcpf(fabsf(rz.x)), __builtin_amdgcn_rcpf(fabsf(rz.y))};
+    const f2 rb = {__builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.x), dr.dw3)), __builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.y), dr.dw3))};
+    const f2 arg = pk_fma(pk_mul(pk_mul(d2, rb), rb), splat(-0.5f * 1.44269504088896341f), splat(dr.lg));
+    const f2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    return pk_mul(pk_mul(rdz, rdz), ex);
+}
+
 // The downwash of an N = 64 env from its LDS tile (see tile64_write), evaluated once per unordered pair: see k_step.
 // t = the env's tile + lane.  Two neighbours per pass through the packed float32 instructions; the reciprocals, the
 // exponential and the selects stay per neighbour.  Per pair operation for operation the arithmetic of downwash_mag2;
@@ -519,8 +530,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // N = 64 (one env per wave): the three-array tile of the packed pair loop (tile64_write); any other N, and the
     // MRS_EXACT_F32 build's all-pairs loop: one float4 per agent
     const bool tile_soa = n64 && !MRS_EXACT_F32;
+    // an env that spans several waves (64 < N <= 256, fused kernel) runs the symmetric ring below on the same kind of
+    // tile: three arrays of 2N floats per env, every coordinate twice, so that neighbours k and k+1 of a lane are one
+    // ds_read2_b32 at an un-wrapped index (6N floats per env; epb * N <= BLOCK, and the tile region holds 8 * BLOCK)
+    const bool ring = !MRS_EXACT_F32 && FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
+    float *const ring_x = reinterpret_cast<float *>(lds_tile) + el * 6 * AN;
     if (tile_soa) tile64_write(lds_tile, el, i, (float)p[0], (float)p[1], (float)p[2]);
-    else lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    else if (ring) {
+        if (live) {
+            ring_x[i] = ring_x[AN + i] = (float)p[0]; ring_x[2 * AN + i] = ring_x[3 * AN + i] = (float)p[1];
+            ring_x[4 * AN + i] = ring_x[5 * AN + i] = (float)p[2];
+        }
+    } else lds_tile[tid] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
     TL(10); // positions arrived and staged
     // MRS_LATE_LOADS (N = 64): the ten remaining state words are not even issued here but one per pass of the pair loop
     // (downwash_ring64's hook).  All 16 waves of a CU reach this point together and the CU's address unit takes ~16
@@ -577,28 +598,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // order (deterministic).  Half the transcendental work of the all-pairs loop (N = 256 x 1024 envs: 83.4 -> 77.2 us).
     // Every thread runs the loop: the barriers are workgroup-wide and the trip count depends on N only.
     constexpr int RING_R = 8;
-    const bool ring = FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
     if (ring) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
-        const float4 *tile_env = lds_tile + el * AN;
-        const DownwashConst &dc = A.dc;
-        const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
+        const float *tx = ring_x + i, *ty = ring_x + 2 * AN + i, *tz = ring_x + 4 * AN + i; // neighbour i + k at offset k, no wrap
+        const DownwashRegs dr = downwash_regs(A.dc);
+        const f2 mx = splat((float)p[0]), my = splat((float)p[1]), mz = splat((float)p[2]);
         const int half = (AN - 1) / 2;
         for (int k0 = 1; k0 <= half; k0 += RING_R) {
             float *buf = xb + (((k0 - 1) / RING_R) & 1) * (RING_R * BLOCK);
             float acc32 = 0.f;
 #pragma unroll
-            for (int r = 0; r < RING_R; ++r) {
+            for (int r = 0; r < RING_R; r += 2) { // two ring distances per pass on the packed float32 instructions
                 const int k = k0 + r;
                 if (k <= half && doit) {
+                    const f2 rx = pk_sub(f2{tx[k], tx[k + 1]}, mx), ry = pk_sub(f2{ty[k], ty[k + 1]}, my), rz = pk_sub(f2{tz[k], tz[k + 1]}, mz);
+                    const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+                    const f2 m = downwash_mag2_pk(d2, rz, dr);
                     int j = i + k;
                     j = j >= AN ? j - AN : j;
-                    const float4 pj = tile_env[j];
-                    const float dz = pj.z - mz;
-                    const float F = downwash_mag(pj.x - mx, pj.y - my, fabsf(dz), dc); // 0 when dz == 0
-                    const bool above = dz > 0.f;
-                    acc32 += above ? F : 0.f;
-                    buf[r * BLOCK + el * AN + j] = above ? 0.f : F;
+                    {   // the neighbour is above: the term is this lane's; below: the neighbour's (0 when dz == 0)
+                        const bool near = d2.x < 100.f;
+                        acc32 += (rz.x > 0.f && near) ? -m.x : 0.f;
+                        buf[r * BLOCK + el * AN + j] = (rz.x < 0.f && near) ? -m.x : 0.f;
+                    }
+                    if (k + 1 <= half) {
+                        const int j1 = (j + 1 == AN) ? 0 : j + 1;
+                        const bool near = d2.y < 100.f;
+                        acc32 += (rz.y > 0.f && near) ? -m.y : 0.f;
+                        buf[(r + 1) * BLOCK + el * AN + j1] = (rz.y < 0.f && near) ? -m.y : 0.f;
+                    }
                 }
             }
             __syncthreads();
@@ -608,16 +636,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             downwash_acc += (double)acc32;
         }
         if (!(AN & 1) && doit) { // antipodal pair: evaluated by both ends, each keeping its own term
-            int j = i + AN / 2;
-            j = j >= AN ? j - AN : j;
-            const float4 pj = tile_env[j];
-            const float dz = pj.z - mz;
-            downwash_acc += (double)(dz > 0.f ? downwash_mag(pj.x - mx, pj.y - my, dz, dc) : 0.f);
+            const int k = AN / 2;
+            const float rx = tx[k] - (float)p[0], ry = ty[k] - (float)p[1], dz = tz[k] - (float)p[2];
+            downwash_acc += (double)(dz > 0.f ? downwash_mag2(__builtin_fmaf(ry, ry, rx * rx), dz, dr.dw2, dr.dw3, dr.lg) : 0.f);
         }
         __syncthreads(); // the exchange buffer is the state stash of the contact phase
     }
-#else
-    const bool ring = false;
 #endif
     if (late_loads && live && !doit) { // a masked or NaN-action env keeps its state: loaded here for the outputs
         q[0] = wb.quat[la]; q[1] = (wb.quat + T)[la]; q[2] = (wb.quat + 2 * T)[la]; q[3] = (wb.quat + 3 * T)[la];
