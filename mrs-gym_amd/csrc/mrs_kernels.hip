@@ -345,7 +345,6 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 {
     const DownwashRegs dr = downwash_regs(dc);
     const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
-    const f2 lg = splat(dr.lg), ce = splat(-0.5f * 1.44269504088896341f);
     f2 acc = {0.f, 0.f}; // .x: the terms this lane keeps, .y: the terms handed to it -- one packed add per pair
     float pend = 0.f;
     double dacc = 0.;
@@ -364,14 +363,7 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
         pend = f_in;
         if ((k & 7) == 0) { dacc += (double)f32add(acc.x, acc.y); acc = f2{0.f, 0.f}; } // short float32 partial sums
     };
-    // |dz| enters only through the abs operand modifier of v_rcp_f32 / v_fma_f32 (the packed forms have none)
-    auto mag2 = [&](f2 d2, f2 rz) {
-        const f2 rdz = {__builtin_amdgcn_rcpf(fabsf(rz.x)), __builtin_amdgcn_rcpf(fabsf(rz.y))};
-        const f2 rb = {__builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.x), dr.dw3)), __builtin_amdgcn_rcpf(__builtin_fmaf(dr.dw2, fabsf(rz.y), dr.dw3))};
-        const f2 arg = pk_fma(pk_mul(pk_mul(d2, rb), rb), ce, lg);
-        const f2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-        return pk_mul(pk_mul(rdz, rdz), ex);
-    };
+    auto mag2 = [&](f2 d2, f2 rz) { return downwash_mag2_pk(d2, rz, dr); };
 #pragma unroll
     for (int k = 1; k < 31; k += 2) {
         hook(k >> 1);
