@@ -18,8 +18,12 @@ CONFIGS = [  # label, E, N, action type, adjacency
     ("C3  N=64 x4096, set_target_vel, A (bench line)", 4096, 64, "set_target_vel", True),
     ("C4  N=256 x1024, set_control, A", 1024, 256, "set_control", True),
     ("C5/8 N=64 x4096, set_target_pos, A", 4096, 64, "set_target_pos", True),
-    ("    N=3 x87381, set_target_vel, A", 87381, 3, "set_target_vel", True),
-    ("    N=12 x21845, set_target_vel, A", 21845, 12, "set_target_vel", True),
+    # other N: 256-thread workgroups of floor(256/N) envs, 4 resident per CU -- swarm sizes that fill 1024 workgroups exactly,
+    # and the same agent count in 1029 / 1041 workgroups (the few extra ones run as a second round: +60 % for the launch)
+    ("    N=3 x87040, set_target_vel, A", 87040, 3, "set_target_vel", True),
+    ("    N=3 x87381 (1029 workgroups)", 87381, 3, "set_target_vel", True),
+    ("    N=12 x21504, set_target_vel, A", 21504, 12, "set_target_vel", True),
+    ("    N=12 x21845 (1041 workgroups)", 21845, 12, "set_target_vel", True),
     ("    N=1024 x256, set_target_vel, A (three launches)", 256, 1024, "set_target_vel", True),
 ]
 for label, E, N, atype, want_adj in CONFIGS:

@@ -11,7 +11,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tes
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT
 from util_scenarios import ActionStream, grid_spawn
-E, N = 4096, 64
+E, N = int(os.environ.get("E", 4096)), int(os.environ.get("N", 64))
 pos, eul = grid_spawn(E, N); z = np.zeros((E, N, 3), np.float32)
 sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", want_rpm=True)
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
@@ -23,7 +23,8 @@ for T0 in (200, 800):
     for t in range(T0 if T0 == 200 else 600):
         sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
     torch.cuda.synchronize()
-    full = sh.rpm.flatten()[:E * 16].view(E, 16).cpu().numpy()
+    W = E if N == 64 else -(-E // (256 // N)) * 4          # waves of the launch (N = 64: one per env; else 256-thread workgroups)
+    full = sh.rpm.flatten()[:W * 16].view(W, 16).cpu().numpy()
     tl = full[:, :9]      # one wave per env at N=64
     if full[:, 9].max() > 0:
         print("  head of the kernel: arguments arrived + loads issued at %.0f [%.0f .. %.0f], positions staged at %.0f [%.0f .. %.0f]" % (
@@ -34,8 +35,8 @@ for T0 in (200, 800):
             print("  wave starts after the first wave's: median %.2f us, 90%% %.2f us, last %.2f us; wave ends: first %.2f us, median %.2f us, last %.2f us" % (
                 np.median(t0 - first) / 100, np.percentile(t0 - first, 90) / 100, (t0.max() - first) / 100,
                 (t1.min() - first) / 100, np.median(t1 - first) / 100, (t1.max() - first) / 100))
-    print("after %d steps (clock64 ticks; mean over %d waves, [min..max] of the cumulative stamp)" % (T0, E))
-    prev = np.zeros(E)
+    print("after %d steps (clock64 ticks; mean over %d waves, [min..max] of the cumulative stamp)" % (T0, len(tl)))
+    prev = np.zeros(len(tl))
     for k, nm in enumerate(names):
         col = tl[:, k]
         valid = col > 0
