@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _shard(E, N, fields=("pos", "vel")):
+def _shard(E, N, fields=("pos", "vel"), rounded=False):
     import mrsgym_amd
     sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", obs_fields=fields, want_rpm=True)
     p = mrsgym_amd.default_params()
+    p.round_euler_readback = int(rounded)   # the attitude controller's literal float32 rounding of the Euler read-back
     p.enable_contact = 0
     p.ground_z = -1e9            # only the rotor speeds are looked at; keep the ground out of it
     sh.set_params(p)
@@ -102,8 +103,9 @@ def test_F2_nnls_branch_on_gpu(golden_dir):
 MODES = {"pos": "set_target_pos", "vel": "set_target_vel", "accel": "set_target_accel", "ori": "set_target_ori"}
 
 
+@pytest.mark.parametrize("rounded", [False, True])
 @pytest.mark.parametrize("mode", ["pos", "vel", "accel", "ori"])
-def test_F1_quadcontrol_cascade_on_gpu(golden_dir, mode):
+def test_F1_quadcontrol_cascade_on_gpu(golden_dir, mode, rounded):
     """Every F1 tuple is one quadcopter: set_state(pos, euler, vel, angvel) -> mrs_step<set_target_*> -> rpm, five
     consecutive calls (the PID planes persist across set_state, like the reference's QuadControl object).
     What the device controller sees is the float32 read-back of the float64 state (Object.py:78-97): the euler
@@ -121,7 +123,7 @@ def test_F1_quadcontrol_cascade_on_gpu(golden_dir, mode):
     assert E * N == n
     large = (np.arange(n) % 4 == 0)                      # gen_golden: a quarter of the cases at large attitude
     assert np.abs(d["ori"][large][..., :2]).max() > 1.0
-    sh = _shard(E, N, fields=("pos", "ori", "vel", "angvel"))
+    sh = _shard(E, N, fields=("pos", "ori", "vel", "angvel"), rounded=rounded)   # both controller forms (deviation 7)
     ctl = [oracle.Controller() for _ in range(n)]
     obs = torch.zeros(E, N, 12, device="cuda:0")
     worst_ref, worst_orc = 0.0, 0.0
