@@ -573,11 +573,13 @@ MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1,
 //   integrate_velocity : ABA + applyDeltaVee           -> unconstrained v, w
 //   contact_solve      : only for bodies near the ground (needs_contact)
 //   integrate_pose     : stepPositionsMultiDof with the final v, w
-MRS_DEV bool needs_contact(const MrsParams &P, double pz)
+// park_z = ground_z + sqrt(coll_radius^2 + coll_half_len^2) + contact_threshold, formed once per call on the host (as a
+// per-lane expression it was a correctly rounded float64 square root, ~18 vector instructions, in every step of every
+// body).  A body within one rounding of the limit may fall on the other side than it did with the subtraction form: it
+// has no rim point within the threshold either way, so its solve does nothing.
+MRS_DEV bool needs_contact(int enable_contact, double park_z, double pz)
 {
-    if (!P.enable_contact) return false;
-    const double bound = sqrt(P.coll_radius * P.coll_radius + P.coll_half_len * P.coll_half_len);
-    return !(pz - bound - P.contact_threshold > P.ground_z);
+    return enable_contact && !(pz > park_z);
 }
 
 MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const double q[4], double v[3], double w[3],

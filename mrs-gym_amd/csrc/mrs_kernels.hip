@@ -37,6 +37,7 @@ struct StepArgs {
     int do_adj, comm_inf;
     float d2_thresh;
     double hclip;
+    double park_z;      // bodies with their centre at or below this height go through the contact solve (needs_contact)
     Recips rc;
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
@@ -829,8 +830,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
         TL(3); // forces + velocity integration
         if (FUSED) {
-            parked = needs_contact(A.P, p[2]);
-        } else if (needs_contact(A.P, p[2])) {
+            parked = needs_contact(A.P.enable_contact, A.park_z, p[2]);
+        } else if (needs_contact(A.P.enable_contact, A.park_z, p[2])) {
             // near the ground: queue the body for k_contact (compacted: the solver's cost scales with the
             // number of grounded bodies, and its registers stay out of this kernel).  Its pre-step pose and
             // unconstrained velocities travel in the slot-indexed planes of contact_state, so k_contact
@@ -1484,6 +1485,7 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
 {
     memset(&A, 0, sizeof(A));
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
+    A.park_z = h->P.ground_z + std::sqrt(h->P.coll_radius * h->P.coll_radius + h->P.coll_half_len * h->P.coll_half_len) + h->P.contact_threshold;
     { // Quadcopter.py:103-110 constants of the pair term, float32 like the reference's arithmetic (see DownwashConst)
         DownwashConst &c = A.dc;
         c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
