@@ -1335,7 +1335,7 @@ extern "C" int mrs_params_default(MrsParams *p)
     p->inertia[2] = p->mass / 12.0 * (lx * lx + lx * lx);
     p->lin_damp = (double)0.04f; p->ang_damp = (double)0.04f; p->max_coord_vel = 100.0; p->use_gyro = 1;
     p->ground_z = 0.5; p->friction = 1.5 * 0.5; p->erp = 0.2; p->contact_threshold = 0.02; // plane.urdf:5,24
-    p->solver_iters = 10; p->enable_contact = 1;
+    p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
     return 0;
 }
 
