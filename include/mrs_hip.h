@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRS_ABI_VERSION 1
+#define MRS_ABI_VERSION 2
 
 /* error codes (negative) */
 #define MRS_E_ARG (-1)        /* bad argument (NULL, size, unsupported N) */
@@ -83,6 +83,11 @@ typedef struct MrsParams {
      * float32 quaternion read-back -- they differ by <= 2^-24 relative per angle, the reference's own read-back noise
      * (deviation 7); saves ~130 float64 instructions per agent-step. */
     int32_t round_euler_readback;
+    /* 1 (default): quad-quad contact -- every quadcopter a sphere of coll_radius; a pair within contact_threshold gets,
+     * per body, half of the normal velocity change that closes the gap this step / pushes the overlap out with erp (one
+     * pass, no friction, no torque; the build's own model).  Needs enable_contact. */
+    int32_t pair_contact;
+    int32_t reserved1;
 } MrsParams;
 
 /* Device buffers of one swarm shard (all borrowed).  Optional members may be NULL. */

@@ -38,6 +38,11 @@ struct StepArgs {
     float d2_thresh;
     double hclip;
     double park_z;      // bodies with their centre at or below this height go through the contact solve (needs_contact)
+    // quad-quad contact (MrsParams.pair_contact, mrs_device.hpp pair_contact_term): an env's flag says that the adjacency
+    // pass over the positions it is starting from saw a pair within contact range; only flagged envs look for partners
+    int *pair_flag;     // [E] library workspace, or null when the model is off
+    float pair_rc2;     // (2 r + contact_threshold)^2
+    float pair_r2, pair_inv_dt, pair_erp_dt; // 2 r, 1 / dt, erp / dt
     Recips rc;
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
@@ -186,8 +191,13 @@ __device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
 // both come from five packed instructions, and each verdict lands at a compile-time bit position (one select and one
 // OR; the row's own bit is cleared once at the end).  Was: one float4 read, six scalar operations, two compares and a
 // 64-bit variable shift per agent -- 13 vector instructions per pair against 6 (N = 256: 68 -> see DESIGN.md section 6).
-__device__ __forceinline__ void adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row)
+__device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row)
 {
+    // returns whether another agent of the env is within quad-quad contact range (A.pair_rc2; coincident centres excluded)
+    bool hit = false;
+    const bool want_hit = A.pair_flag != nullptr;
+    float rc2 = A.pair_rc2;
+    asm volatile("" : "+v"(rc2));
     float thr = thr_s;
     asm volatile("" : "+v"(thr)); // not re-read from the argument segment inside the loop (see adjacency_phase)
     const bool inf = A.comm_inf != 0;
@@ -195,7 +205,7 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, float thr_s, co
     for (int wd = 0; wd < A.W; ++wd) {
         const int j0 = wd * 64, jn = min(64, A.N - j0);
         uint32_t half[2] = {0u, 0u};
-        if (inf) {
+        if (inf && !want_hit) {
             const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
             half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
         } else if (jn == 64) {
@@ -208,6 +218,7 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, float thr_s, co
                     const f2 dx = pk_sub(mx, f2{tx[j], tx[j + 1]}), dy = pk_sub(my, f2{ty[j], ty[j + 1]}), dz = pk_sub(mz, f2{tz[j], tz[j + 1]});
                     const f2 d2 = pk_fma(dz, dz, pk_fma(dy, dy, pk_mul(dx, dx)));
                     bits |= (d2.x <= thr ? (1u << jj) : 0u) | (d2.y <= thr ? (2u << jj) : 0u);
+                    hit |= (d2.x <= rc2 && d2.x > 0.f) || (d2.y <= rc2 && d2.y > 0.f);
                 }
                 half[hh] = bits;
             }
@@ -217,12 +228,18 @@ __device__ __forceinline__ void adjacency_row(const StepArgs &A, float thr_s, co
                 const float dx = f32sub(me.x, tx[j]), dy = f32sub(me.y, ty[j]), dz = f32sub(me.z, tz[j]);
                 const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
                 if (d2 <= thr) half[jj >> 5] |= 1u << (jj & 31);
+                hit |= d2 <= rc2 && d2 > 0.f;
             }
+        }
+        if (inf) { // ones - eye whatever the positions are (the loops above ran for the contact range only)
+            const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
+            half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
         }
         uint64_t bits = ((uint64_t)half[1] << 32) | half[0];
         if ((unsigned)(i - j0) < 64u) bits &= ~(1ull << (i - j0)); // ones - eye (MRS.py:118-119, :123)
-        row[wd] = bits;
+        if (row) row[wd] = bits;
     }
+    return hit && want_hit;
 }
 
 
@@ -255,13 +272,24 @@ __device__ __forceinline__ void tile64_rel2(const float *t, int k, f2 mx, f2 my,
     rx = pk_sub(f2{t[k], t[k + 1]}, mx); ry = pk_sub(f2{t[128 + k], t[128 + k + 1]}, my); rz = pk_sub(f2{t[256 + k], t[256 + k + 1]}, mz);
 }
 
+// StepArgs.pair_flag[e], N = 64: exactly ONE pair of the env is within contact range, agents (flag & 63) and (flag >> 8 & 63).
+// By far the common case among the flagged envs, and the step kernel's duration is that of its slowest wave: a wave that scans
+// its env (63 neighbours per lane, alone on its SIMD by then) lengthened every launch by ~1.5 us; with the pair named it
+// evaluates one term.  (Not a bit of 0x01010101, the "unknown" pattern that hipMemset(.., 1, ..) leaves.)
+#define MRS_PAIR_SINGLE 0x40000000
+
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
+// Also (A.pair_flag): notes per env whether any pair of it is within quad-quad contact range of these positions -- the
+// squared distances are formed here anyway -- for the step that starts from them.  row may be null (flag only).
 template <int BLOCK, int NFIX = 0>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
-                                                uint64_t *row, float4 mine)
+                                                uint64_t *row, float4 mine, int e)
 {
     const bool n64 = (NFIX == 64 || A.N == 64);
+    const bool want_hit = A.pair_flag != nullptr;
+    int *const hit_flag = reinterpret_cast<int *>(lds_tile) + 3 * BLOCK; // generic N: one word per env slot, behind the three arrays
+    if (!n64 && want_hit && tid < A.epb) hit_flag[tid] = 0;
     float *const gx = reinterpret_cast<float *>(lds_tile); // any other N: three arrays of BLOCK floats (see adjacency_row)
     if (n64) tile64_write(lds_tile, el, i, mine.x, mine.y, mine.z);
     else { gx[tid] = mine.x; gx[BLOCK + tid] = mine.y; gx[2 * BLOCK + tid] = mine.z; }
@@ -290,12 +318,18 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             // cross-lane transfer in flight: the loop then runs one pair per memory round trip.
             float thr = thr_s;
             asm volatile("" : "+v"(thr));
+            float rc2 = A.pair_rc2;
+            asm volatile("" : "+v"(rc2));
+            uint32_t hm = 0; // neighbours k = 1..31 within quad-quad contact range, bit k; the antipode k = 32 in `ht`
+            bool ht = false;
             // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
-            if (!comm_inf) {
+            // (unless the contact flag wants the distances)
+            if (!comm_inf || want_hit) {
                 const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
                 // (consuming the handed-over verdicts one pass late, as the downwash loop does with its terms, was measured:
                 // no gain, 26.3 against 26.3 us per step)
                 auto verdict = [&](int k, float d2) {
+                    hm |= d2 <= rc2 ? (1u << k) : 0u;
                     const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
                     lo |= bit;
                     hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
@@ -314,14 +348,39 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                     const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
                     verdict(31, d2.x);
                     top = d2.y <= thr ? 1u : 0u;
+                    ht = d2.y <= rc2;
                 }
+            }
+            if (want_hit) { // the wave is the env; every unordered pair was tested once (the antipodes by both ends)
+                const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
+                const uint64_t testers = __builtin_amdgcn_ballot_w64(cnt != 0);
+                int flag = 0;
+                if (testers != 0) { // rare (a fraction of a percent of the envs of the benchmark rollout)
+                    flag = 1; // several pairs: the step scans the env
+                    const int a = __builtin_ctzll(testers), nb = __builtin_popcountll(testers);
+                    if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
+                        const uint32_t hma = (uint32_t)__builtin_amdgcn_readlane((int)hm, a);
+                        if (nb == 1 && hma != 0) {
+                            flag = MRS_PAIR_SINGLE | a | (((a + __builtin_ctz(hma)) & 63) << 8);
+                        } else if (nb == 2 && a < 32 && __builtin_amdgcn_ballot_w64(ht && hm == 0) == testers && (testers >> (a + 32)) == 1ull) {
+                            flag = MRS_PAIR_SINGLE | a | ((a + 32) << 8);
+                        }
+                    }
+                }
+                if (lane == 0) A.pair_flag[e] = flag;
             }
             const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
             const uint64_t rel = comm_inf ? ~1ull : (((uint64_t)hi << 32) | lo);
             if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
         }
-    } else if (live) {
-        adjacency_row(A, thr_s, gx + el * A.N, gx + BLOCK + el * A.N, gx + 2 * BLOCK + el * A.N, i, mine, row);
+    } else {
+        bool hit = false;
+        if (live) hit = adjacency_row(A, thr_s, gx + el * A.N, gx + BLOCK + el * A.N, gx + 2 * BLOCK + el * A.N, i, mine, row);
+        if (want_hit) { // workgroup-uniform: every thread takes the barrier
+            if (hit) atomicOr(&hit_flag[el], 1);
+            __syncthreads();
+            if (live && i == 0) A.pair_flag[e] = hit_flag[el];
+        }
     }
 }
 
@@ -385,6 +444,23 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
         dacc += (double)f32add(acc.x, acc.y);
     }
     return dacc;
+}
+
+// Quad-quad contact of lane i with one other agent (oracle/mrs_oracle.c:pair_contact, the same float32 operations): the
+// centres' difference r = p_i - p_j, both unconstrained velocities as float32; adds this lane's half of the correction.
+__device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, float ry, float rz, float ux, float uy, float uz, float dv[3])
+{
+    const float d2 = f32fma(rz, rz, f32fma(ry, ry, f32mul(rx, rx)));
+    if (!(d2 <= A.pair_rc2) || !(d2 > 0.f)) return;
+    const float d = f32sqrt(d2), rd = f32div(1.0f, d);
+    const float nx = f32mul(rx, rd), ny = f32mul(ry, rd), nz = f32mul(rz, rd);
+    const float vn = f32fma(uz, nz, f32fma(uy, ny, f32mul(ux, nx)));
+    const float gap = f32sub(d, A.pair_r2);
+    const float rhs = f32sub(-vn, f32mul(gap, gap > 0.f ? A.pair_inv_dt : A.pair_erp_dt));
+    if (rhs > 0.f) {
+        const float h = f32mul(0.5f, rhs);
+        dv[0] = f32fma(h, nx, dv[0]); dv[1] = f32fma(h, ny, dv[1]); dv[2] = f32fma(h, nz, dv[2]);
+    }
 }
 
 // ------------------------------------------------------------------------------------ step kernel
@@ -828,6 +904,49 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         }
         TL(22); // rotor forces, ground effect, drag
         integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
+    }
+    // ---- quad-quad contact on the unconstrained velocities (only envs whose flag is set; see StepArgs.pair_flag).  The
+    // agents' float32 velocities go through the position tile's spare space: N = 64 and the multi-wave ring keep every
+    // coordinate twice (the second copies are free once the downwash loop is through), the float4 tile has its
+    // second half.  An env is a wave at N = 64 (wave-local sync); otherwise the branch is made workgroup-uniform.
+    if (A.pair_flag != nullptr) {
+        // did the adjacency pass over the positions this step started from see a pair of this env within contact range?
+        // (loading the flag earlier -- after the downwash loop, after the controller -- was measured: no difference)
+        const int pf = doit ? A.pair_flag[e] : 0;
+        const bool mine = doit && pf != 0;
+        const bool any = n64 ? (__builtin_amdgcn_ballot_w64(mine) != 0) : (__syncthreads_or(mine) != 0);
+        if (any) {
+            float *const t64 = tile64(lds_tile, el);
+            if (tile_soa) { t64[64 + i] = (float)v[0]; t64[192 + i] = (float)v[1]; t64[320 + i] = (float)v[2]; }
+            else if (ring) { if (live) { ring_x[AN + i] = (float)v[0]; ring_x[3 * AN + i] = (float)v[1]; ring_x[5 * AN + i] = (float)v[2]; } }
+            else lds_tile[BLOCK + tid] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.f);
+            if (n64) wave_lds_sync(); else __syncthreads();
+            const float px = (float)p[0], py = (float)p[1], pz = (float)p[2];
+            const float vx = (float)v[0], vy = (float)v[1], vz = (float)v[2];
+            float dv[3] = {0.f, 0.f, 0.f};
+            if (tile_soa && (pf & MRS_PAIR_SINGLE)) { // one pair in the env (the flag is the wave's): its two agents, one term each
+                const int i0 = pf & 63, j0 = (pf >> 8) & 63;
+                if (i == i0 || i == j0) {
+                    const int j = i == i0 ? j0 : i0;
+                    pair_contact_term(A, f32sub(px, t64[j]), f32sub(py, t64[128 + j]), f32sub(pz, t64[256 + j]),
+                                      f32sub(vx, t64[64 + j]), f32sub(vy, t64[192 + j]), f32sub(vz, t64[320 + j]), dv);
+                }
+            } else if (mine) {
+                for (int jj = 1; jj < AN; ++jj) {
+                    int j = i + jj;
+                    j = j >= AN ? j - AN : j;
+                    float qx, qy, qz, wx, wy, wz;
+                    if (tile_soa) { qx = t64[j]; qy = t64[128 + j]; qz = t64[256 + j]; wx = t64[64 + j]; wy = t64[192 + j]; wz = t64[320 + j]; }
+                    else if (ring) { qx = ring_x[j]; qy = ring_x[2 * AN + j]; qz = ring_x[4 * AN + j]; wx = ring_x[AN + j]; wy = ring_x[3 * AN + j]; wz = ring_x[5 * AN + j]; }
+                    else { const float4 a = lds_tile[el * AN + j], b = lds_tile[BLOCK + el * AN + j]; qx = a.x; qy = a.y; qz = a.z; wx = b.x; wy = b.y; wz = b.z; }
+                    pair_contact_term(A, f32sub(px, qx), f32sub(py, qy), f32sub(pz, qz), f32sub(vx, wx), f32sub(vy, wy), f32sub(vz, wz), dv);
+                }
+            }
+            v[0] += (double)dv[0]; v[1] += (double)dv[1]; v[2] += (double)dv[2];
+            if (!n64) __syncthreads(); // the tile's second half / second copies are somebody else's scratch from here on
+        }
+    }
+    if (doit) {
         TL(3); // forces + velocity integration
         if (FUSED) {
             parked = needs_contact(A.P.enable_contact, A.park_z, p[2]);
@@ -925,9 +1044,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
-        if (A.do_adj)
-            adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)AW,
-                                         make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+        if (A.do_adj || A.pair_flag != nullptr) {
+            // (the env index is formed again from an opaque copy of the thread index: kept live from the top of the kernel
+            // it was the one register too many across the contact sweeps)
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int e2 = blockIdx.x * AEPB + (n64 ? (t2 >> 6) : el);
+            adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
+                                         A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
+                                         make_float4((float)p[0], (float)p[1], (float)p[2], 0.f), e2);
+        }
         TL(8); // observation + adjacency
 #ifdef MRS_TIMELINE
         if (tl && (tid & 63) == 0) tl[12] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF);
@@ -1004,7 +1130,9 @@ __global__ __launch_bounds__(BLOCK) void k_observe_adj(const StepArgs A)
         if (nw) { w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la]; }
     }
     if (A.b.obs && live && A.n_obs > 0) write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
-    if (A.do_adj) adjacency_phase<BLOCK>(A, A.d2_thresh, A.comm_inf != 0, lds_tile, tid, el, i, live, wb.adj + la * (unsigned)A.W, make_float4((float)p[0], (float)p[1], (float)p[2], 0.f));
+    if (A.do_adj || A.pair_flag != nullptr)
+        adjacency_phase<BLOCK>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live, A.do_adj ? wb.adj + la * (unsigned)A.W : nullptr,
+                               make_float4((float)p[0], (float)p[1], (float)p[2], 0.f), e);
 }
 
 // packed (M,N,W) -> dense float32 (M,N,N).  N % 4 == 0: one thread per four consecutive columns (a 16-byte store;
@@ -1282,6 +1410,7 @@ struct MrsHandle {
     double *cs;         // device workspace: [13][T] parked states of the listed bodies
     bool fused;         // one-launch step (256-thread workgroups; MRS_STEP_SPLIT=1 keeps the three-launch form)
     unsigned step_parity;
+    int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
     float4 *eul_key;    // device workspace, fused step: Euler angles carried from a step's observation slice to the next
     double *eul_ang;    //   step's attitude controller (see MRS_EUL_CARRY): float32 quaternion key [T], float64 angles [3][T]
 };
@@ -1335,7 +1464,7 @@ extern "C" int mrs_params_default(MrsParams *p)
     p->inertia[2] = p->mass / 12.0 * (lx * lx + lx * lx);
     p->lin_damp = (double)0.04f; p->ang_damp = (double)0.04f; p->max_coord_vel = 100.0; p->use_gyro = 1;
     p->ground_z = 0.5; p->friction = 1.5 * 0.5; p->erp = 0.2; p->contact_threshold = 0.02; // plane.urdf:5,24
-    p->solver_iters = 10; p->enable_contact = 1;
+    p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
     return 0;
 }
 
@@ -1435,7 +1564,12 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
-    h->eul_key = nullptr; h->eul_ang = nullptr;
+    h->eul_key = nullptr; h->eul_ang = nullptr; h->pair_flag = nullptr;
+    if (e == hipSuccess) {
+        e = hipMalloc((void **)&h->pair_flag, (size_t)n_envs * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(h->pair_flag, 1, (size_t)n_envs * sizeof(int)); // nothing known yet: every env looks
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
     if (e == hipSuccess && h->fused && MRS_EUL_CARRY) {
         const size_t T = (size_t)n_envs * n_agents;
         e = hipMalloc((void **)&h->eul_key, T * sizeof(float4));
@@ -1448,6 +1582,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (h->cs) (void)hipFree(h->cs);
         if (h->eul_key) (void)hipFree(h->eul_key);
         if (h->eul_ang) (void)hipFree(h->eul_ang);
+        if (h->pair_flag) (void)hipFree(h->pair_flag);
         (void)hipSetDevice(cur);
         delete h;
         return hipfail(e, "mrs_create workspace");
@@ -1460,8 +1595,9 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
-    if (h->ws || h->cs || h->eul_key || h->eul_ang) {
+    if (h->ws || h->cs || h->eul_key || h->eul_ang || h->pair_flag) {
         DeviceGuard dg(h->device);
+        if (h->pair_flag) (void)hipFree(h->pair_flag);
         if (h->eul_key) (void)hipFree(h->eul_key);
         if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->ws) (void)hipFree(h->ws);
@@ -1486,6 +1622,10 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
     memset(&A, 0, sizeof(A));
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
     A.park_z = h->P.ground_z + std::sqrt(h->P.coll_radius * h->P.coll_radius + h->P.coll_half_len * h->P.coll_half_len) + h->P.contact_threshold;
+    A.pair_flag = (h->P.enable_contact && h->P.pair_contact && h->N > 1) ? h->pair_flag : nullptr;
+    A.pair_r2 = 2.0f * (float)h->P.coll_radius;
+    A.pair_rc2 = (A.pair_r2 + (float)h->P.contact_threshold) * (A.pair_r2 + (float)h->P.contact_threshold);
+    A.pair_inv_dt = (float)(1.0 / h->P.dt); A.pair_erp_dt = (float)(h->P.erp / h->P.dt);
     { // Quadcopter.py:103-110 constants of the pair term, float32 like the reference's arithmetic (see DownwashConst)
         DownwashConst &c = A.dc;
         c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
@@ -1674,6 +1814,15 @@ static int launch_set(MrsHandle *, const SetArgs &S, hipStream_t st)
     return e == hipSuccess ? 0 : hipfail(e, "mrs_set_state launch");
 }
 
+// Positions were rewritten from outside the step (set_state, spawn): every env looks for quad-quad contact partners in its
+// next step (StepArgs.pair_flag); the adjacency pass of that step -- or of mrs_observe / mrs_adjacency -- makes the flags exact again.
+static int pairs_unknown(MrsHandle *h, hipStream_t st, const char *where)
+{
+    if (!h->pair_flag) return 0;
+    hipError_t e = hipMemsetAsync(h->pair_flag, 1, (size_t)h->E * sizeof(int), st);
+    return e == hipSuccess ? 0 : hipfail(e, where);
+}
+
 extern "C" int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos, const float *ori, int ori_kind,
                              const float *vel, const float *angvel, const uint8_t *env_mask, void *stream)
 {
@@ -1684,7 +1833,8 @@ extern "C" int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos
     memset(&S, 0, sizeof(S));
     S.b = *b; S.pos = pos; S.ori = ori; S.vel = vel; S.angvel = angvel; S.mask = env_mask; S.ori_kind = ori_kind;
     S.N = h->N; S.T = (size_t)h->E * h->N;
-    return launch_set(h, S, (hipStream_t)stream);
+    const int rc = launch_set(h, S, (hipStream_t)stream);
+    return rc ? rc : pairs_unknown(h, (hipStream_t)stream, "mrs_set_state");
 }
 
 extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, const double *quat,
@@ -1696,7 +1846,8 @@ extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double
     memset(&S, 0, sizeof(S));
     S.b = *b; S.pos64 = pos; S.quat64 = quat; S.vel64 = vel; S.angvel64 = angvel; S.mask = env_mask;
     S.N = h->N; S.T = (size_t)h->E * h->N;
-    return launch_set(h, S, (hipStream_t)stream);
+    const int rc = launch_set(h, S, (hipStream_t)stream);
+    return rc ? rc : pairs_unknown(h, (hipStream_t)stream, "mrs_set_state_f64");
 }
 
 extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream)
@@ -1738,7 +1889,7 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
     const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn launch");
+    return e == hipSuccess ? pairs_unknown(h, (hipStream_t)stream, "mrs_spawn") : hipfail(e, "mrs_spawn launch");
 }
 
 extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *candidates, int n_rounds, int resume, double agent_radius,
@@ -1755,7 +1906,7 @@ extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *ca
     const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hipfail(e, "mrs_spawn_from launch");
+    return e == hipSuccess ? pairs_unknown(h, (hipStream_t)stream, "mrs_spawn_from") : hipfail(e, "mrs_spawn_from launch");
 }
 
 // ---------------------------------------------------------------------------------------------------- sensors

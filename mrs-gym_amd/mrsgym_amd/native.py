@@ -48,6 +48,7 @@ class MrsParams(C.Structure):
         ("use_gyro", C.c_int32), ("enable_contact", C.c_int32),
         ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("contact_threshold", C.c_double),
         ("solver_iters", C.c_int32), ("round_euler_readback", C.c_int32),
+        ("pair_contact", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -100,7 +101,7 @@ def lib():
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
-        if L.mrs_abi_version() != 1:
+        if L.mrs_abi_version() != 2:
             raise MrsNativeError("libmrs_hip.so ABI version mismatch")
         _lib = L
     return _lib

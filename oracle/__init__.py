@@ -43,7 +43,7 @@ class OrcParams(C.Structure):
         ("use_gyro", C.c_int),
         ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double),
         ("contact_threshold", C.c_double),
-        ("solver_iters", C.c_int), ("enable_contact", C.c_int),
+        ("solver_iters", C.c_int), ("enable_contact", C.c_int), ("pair_contact", C.c_int),
     ]
 
 

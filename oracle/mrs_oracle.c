@@ -56,7 +56,7 @@ void orc_params_default(OrcParams *p)
     /* plane.urdf:24 box 30 30 1 centred at the origin, placed at pos 0 (EnvCreator.py:11) */
     p->ground_z = 0.5;
     p->friction = 1.5 * 0.5; /* plane.urdf:5 lateral 1.5 x default link friction 0.5 */
-    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 10; p->enable_contact = 1;
+    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
 }
 
 void orc_derived(const OrcParams *p, double out[7])
@@ -648,8 +648,9 @@ static void contact_solve(const OrcParams *p, const double pos[3], const double 
     }
 }
 
-void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3],
-                   const double fb_ext[3], const double tb_ext[3])
+/* first half of stepSimulation for one body: forces -> unconstrained velocities */
+static void integrate_velocities(const OrcParams *p, const double quat[4], double vel[3], double angvel[3],
+                                 const double fb_ext[3], const double tb_ext[3])
 {
     /* [BULLET-KNOWLEDGE] btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof for a
      * floating base whose links are all fixed and massless, then applyDeltaVeeMultiDof, contact
@@ -681,6 +682,14 @@ void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel
         angvel[k] = clipd(angvel[k] + wdot[k] * dt, -p->max_coord_vel, p->max_coord_vel);
         vel[k] = clipd(vel[k] + vdot[k] * dt, -p->max_coord_vel, p->max_coord_vel);
     }
+}
+
+/* second half: ground contact on the unconstrained velocities, then stepPositionsMultiDof */
+static void contact_and_pose(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3])
+{
+    const double dt = p->dt;
+    double R[9];
+    quat_to_matrix_bullet(quat, R);
     if (p->enable_contact) contact_solve(p, pos, R, vel, angvel);
     /* stepPositionsMultiDof */
     for (int k = 0; k < 3; ++k) pos[k] += dt * vel[k];
@@ -701,6 +710,49 @@ void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel
     double nw2 = dw * qw - axis[0] * qx - axis[1] * qy - axis[2] * qz;
     double nn = sqrt(nx * nx + ny * ny + nz * nz + nw2 * nw2);
     quat[0] = nx / nn; quat[1] = ny / nn; quat[2] = nz / nn; quat[3] = nw2 / nn;
+}
+
+void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3],
+                   const double fb_ext[3], const double tb_ext[3])
+{
+    /* one body on its own (no other body to touch): what the fixture generator's stand-in for p.stepSimulation calls */
+    integrate_velocities(p, quat, vel, angvel, fb_ext, tb_ext);
+    contact_and_pose(p, pos, quat, vel, angvel);
+}
+
+/* Quad-quad contact, the build's own model (SURVEY.md row G says Bullet has hull-hull contacts; its GJK manifold and
+ * solver are not reproducible here): every quadcopter is a sphere of its collision radius; a pair whose spheres are
+ * within the contact threshold gets, per body, half of the normal velocity change that closes the gap this step /
+ * pushes the overlap out with erp -- the same velocity-level right-hand side as the ground rows, one pass, no
+ * friction, no torque.  Geometry and relative velocity in float32 on the float32 read-back positions (what the
+ * kernel's LDS tile holds); applied to the unconstrained velocities, before the ground rows.  opos: pre-step positions. */
+static void pair_contact(const OrcParams *p, int N, float (*opos)[3], double *vel)
+{
+    const float r2 = 2.0f * (float)p->coll_radius, thr = (float)p->contact_threshold;
+    const float rc2 = (r2 + thr) * (r2 + thr), inv_dt = (float)(1.0 / p->dt), erp_dt = (float)(p->erp / p->dt);
+    float dv[N][3];
+    for (int i = 0; i < N; ++i) {
+        dv[i][0] = dv[i][1] = dv[i][2] = 0.f;
+        const float vix = (float)vel[3 * i], viy = (float)vel[3 * i + 1], viz = (float)vel[3 * i + 2];
+        for (int j = 0; j < N; ++j) {
+            if (j == i) continue;
+            const float rx = opos[i][0] - opos[j][0], ry = opos[i][1] - opos[j][1], rz = opos[i][2] - opos[j][2];
+            const float d2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+            if (!(d2 <= rc2) || !(d2 > 0.f)) continue;
+            const float d = sqrtf(d2), rd = 1.0f / d;
+            const float nx = rx * rd, ny = ry * rd, nz = rz * rd;
+            const float ux = vix - (float)vel[3 * j], uy = viy - (float)vel[3 * j + 1], uz = viz - (float)vel[3 * j + 2];
+            const float vn = fmaf(uz, nz, fmaf(uy, ny, ux * nx));
+            const float gap = d - r2;
+            const float rhs = -vn - gap * (gap > 0.f ? inv_dt : erp_dt);
+            if (rhs > 0.f) {
+                const float h = 0.5f * rhs;
+                dv[i][0] = fmaf(h, nx, dv[i][0]); dv[i][1] = fmaf(h, ny, dv[i][1]); dv[i][2] = fmaf(h, nz, dv[i][2]);
+            }
+        }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) vel[3 * i + k] += (double)dv[i][k];
 }
 
 /* -------------------------------------------------------------------- step */
@@ -815,8 +867,10 @@ static void step_env(const OrcParams *p, int N, double *pos, double *quat, doubl
     if (wrench_out)
         for (int i = 0; i < N; ++i)
             for (int k = 0; k < 3; ++k) { wrench_out[6 * i + k] = fb[i][k]; wrench_out[6 * i + 3 + k] = tb[i][k]; }
-    for (int i = 0; i < N; ++i) /* BulletSim.step_sim */
-        orc_integrate(p, &pos[3 * i], &quat[4 * i], &vel[3 * i], &angvel[3 * i], fb[i], tb[i]);
+    /* BulletSim.step_sim: unconstrained velocities of every body, contacts between bodies, ground contact + pose */
+    for (int i = 0; i < N; ++i) integrate_velocities(p, &quat[4 * i], &vel[3 * i], &angvel[3 * i], fb[i], tb[i]);
+    if (p->enable_contact && p->pair_contact && N > 1) pair_contact(p, N, opos, vel);
+    for (int i = 0; i < N; ++i) contact_and_pose(p, &pos[3 * i], &quat[4 * i], &vel[3 * i], &angvel[3 * i]);
 }
 
 void orc_step(const OrcParams *p, int E, int N, double *pos, double *quat, double *vel, double *angvel,

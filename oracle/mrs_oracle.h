@@ -55,6 +55,7 @@ typedef struct OrcParams {
     double ground_z, friction, erp, contact_threshold;
     int solver_iters;
     int enable_contact;
+    int pair_contact;    /* quad-quad contact as a sphere separation constraint (mrs_oracle.c:pair_contact) */
 } OrcParams;
 
 /* Per-agent controller memory (QuadControl.py lazily-created attributes). */

@@ -487,3 +487,83 @@ def test_workgroup_size_does_not_change_results(atype):
             os.environ["MRS_STEP_BLOCK"] = old
     for a, b in zip(out["64"], out["512"]):
         assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
+@pytest.mark.parametrize("with_adj", [True, False])
+@pytest.mark.parametrize("E,N", [(3, 64), (5, 12), (2, 130), (2, 300)])
+def test_quad_quad_contact_matches_oracle(E, N, with_adj):
+    """Row G, second half (the build's own model, oracle: pair_contact): pairs on collision courses -- head-on, crossing
+    vertically, glancing -- among agents that stay far apart, for the one-wave env (N = 64), several envs per wave
+    (N = 12), an env over several waves (N = 130) and the three-launch path (N = 300); with the adjacency output on and
+    off (the contact flags come out of the adjacency pass either way).  Contacts start several steps after set_state,
+    so the first ones are found through the flags of the previous step's pass, not the "look everywhere" state
+    set_state leaves behind.  Float32 exchange of the velocities: 2e-6."""
+    import mrsgym_amd
+    rng = np.random.default_rng(N)
+    side = int(np.ceil(np.sqrt(N)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:N] * 3.0
+    pos = np.zeros((E, N, 3), np.float32); vel = np.zeros((E, N, 3), np.float32)
+    pos[..., :2] = g; pos[..., 2] = 50.0 + rng.uniform(0, 1, (E, N))
+    for e in range(E):      # three pairs per env, indices spread over the env (and, for N > 64, over its waves)
+        a, b = 1, N - 2
+        pos[e, a] = [100, 100 + 3 * e, 60]; pos[e, b] = [100.6, 100 + 3 * e, 60 + 0.02 * e]      # head-on along x
+        vel[e, a] = [1.5, 0, 0]; vel[e, b] = [-1.5, 0, 0]
+        c, d = 0, N // 2
+        pos[e, c] = [200, 200, 61]; pos[e, d] = [200.01, 200.0, 60.5]                              # crossing vertically
+        vel[e, c] = [0, 0, -2.0]; vel[e, d] = [0, 0, 0.5]
+        if N > 6:
+            f, h = 3, N - 4
+            pos[e, f] = [300, 300, 60]; pos[e, h] = [300.5, 300.11, 60]                           # glancing, inside the threshold
+            vel[e, f] = [1.0, 0, 0]; vel[e, h] = [-1.0, 0, 0]
+    eul = np.zeros((E, N, 3), np.float32); z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.set_state(pos=pos, ori=eul, vel=vel, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=vel.astype(np.float64), angvel=z.astype(np.float64))
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    touched = False
+    for t in range(60):
+        sh.step(None, None, adj_out=adj if with_adj else None, comm_range=2.5 if with_adj else float("nan"))
+        sw.step(None, None)
+        g_ = _gpu_state(sh)
+        assert np.abs(g_["pos"] - sw.pos).max() < 2e-6 and np.abs(g_["vel"] - sw.vel).max() < 2e-5, t
+        touched |= bool(np.abs(sw.vel[:, 1, 0] - (1.5)).max() > 0.1)
+    assert touched                                                      # the head-on pairs did collide
+    assert (sw.pos[:, 0, 2] > sw.pos[:, N // 2, 2]).all()               # and nobody passed through anybody
+    d = np.linalg.norm(sw.pos[:, 1] - sw.pos[:, N - 2], axis=-1)
+    assert (d > 0.12 - 1e-5).all()
+
+
+def test_quad_quad_single_pair_of_an_env():
+    """N = 64: the adjacency pass names the pair when exactly one pair of an env is in contact range (MRS_PAIR_SINGLE in
+    mrs_kernels.hip) and the step then evaluates that one term instead of scanning the env.  One head-on pair per env at
+    lane distances that exercise each way the pass can meet it -- antipodes (both ends test it), a pair that wraps around
+    lane 63, neighbours, and a pair whose LOWER lane is the tester's partner -- plus an env with two pairs that come into
+    range at different steps (single, then several, then single again).  Same trajectories as the oracle, which knows
+    nothing about flags."""
+    import mrsgym_amd
+    pairs = [(0, 32), (5, 37), (62, 1), (10, 11), (40, 9), (63, 31), (31, 63)]
+    E, N = len(pairs) + 1, 64
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 2) * 3.0
+    pos = np.zeros((E, N, 3), np.float32); vel = np.zeros((E, N, 3), np.float32)
+    pos[..., :2] = g; pos[..., 2] = 50.0
+    for e, (a, b) in enumerate(pairs):
+        pos[e, a] = [100, 100, 60]; pos[e, b] = [100.5, 100.01 * (1 + 1e-4 * e), 60.02]
+        vel[e, a] = [1.5, 0, 0]; vel[e, b] = [-1.5, 0, 0]
+    e = E - 1                                                      # two pairs, the second one 12 steps behind the first
+    pos[e, 7] = [100, 100, 60]; pos[e, 20] = [100.5, 100.0, 60.01]; vel[e, 7] = [1.5, 0, 0]; vel[e, 20] = [-1.5, 0, 0]
+    pos[e, 50] = [200, 200, 60]; pos[e, 3] = [200.65, 200.0, 60.0]; vel[e, 50] = [1.5, 0, 0]; vel[e, 3] = [-1.5, 0, 0]
+    eul = np.zeros((E, N, 3), np.float32); z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.set_state(pos=pos, ori=eul, vel=vel, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=vel.astype(np.float64), angvel=z.astype(np.float64))
+    for t in range(70):
+        sh.step(None, None)
+        sw.step(None, None)
+        g_ = _gpu_state(sh)
+        assert np.abs(g_["pos"] - sw.pos).max() < 2e-6 and np.abs(g_["vel"] - sw.vel).max() < 2e-5, t
+    for e, (a, b) in enumerate(pairs):
+        assert sw.vel[e, a, 0] < 1.0 and sw.vel[e, b, 0] > -1.0, (e, sw.vel[e, a], sw.vel[e, b])   # they did collide
+        assert np.linalg.norm(sw.pos[e, a] - sw.pos[e, b]) > 0.12 - 1e-5
+    assert sw.vel[E - 1, 7, 0] < 1.0 and sw.vel[E - 1, 50, 0] < 1.0

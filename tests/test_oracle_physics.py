@@ -140,3 +140,46 @@ def test_rest_on_ground_is_stable():
         sw.step(None, None)
     assert sw.pos[0, 0, 2] == pytest.approx(p.ground_z + p.coll_half_len, abs=2e-3)
     assert np.abs(sw.vel[0, 0]).max() < 1e-3 and np.abs(sw.angvel[0, 0]).max() < 1e-3
+
+
+def _two(p, pos, vel):
+    sw = oracle.OracleSwarm(1, 2, params=p)
+    sw.set_state(pos=np.asarray(pos, float).reshape(1, 2, 3), vel=np.asarray(vel, float).reshape(1, 2, 3))
+    return sw
+
+
+def test_quad_quad_contact_is_a_sphere_separation_constraint():
+    """Row G's second half, the build's own model (oracle: pair_contact): spheres of coll_radius, the velocity-level
+    right-hand side of the ground rows, half of the correction per body.  No gravity, no damping, no ground here."""
+    base = dict(gravity=0.0, lin_damp=0.0, ang_damp=0.0, ground_z=-1e9)
+    r2 = 2 * oracle.default_params().coll_radius
+    # (a) head-on along x, closing at 2 m/s: the pair never gets closer than touching, total momentum is kept, and
+    #     the bodies end up at rest relative to each other (restitution 0)
+    sw = _two(_p(**base), [[-0.5, 0, 2], [0.5, 0, 2]], [[1, 0, 0], [-1, 0, 0]])
+    dmin = 1e9
+    for _ in range(100):
+        sw.step(None, None)
+        dmin = min(dmin, np.linalg.norm(sw.pos[0, 0] - sw.pos[0, 1]))
+    assert r2 - 1e-6 < dmin < r2 + 0.021                       # stopped at contact (within the 0.02 threshold)
+    np.testing.assert_allclose(sw.vel[0, 0] + sw.vel[0, 1], 0, atol=1e-6)
+    assert abs(sw.vel[0, 0, 0] - sw.vel[0, 1, 0]) < 1e-5
+    # (b) crossing vertically (what the downwash term used to let through): the upper one comes down on the lower one
+    sw = _two(_p(**base), [[0, 0, 2.5], [0.01, 0, 2.0]], [[0, 0, -1.5], [0, 0, 0]])
+    for _ in range(100):
+        sw.step(None, None)
+    assert sw.pos[0, 0, 2] > sw.pos[0, 1, 2]                    # did not pass through
+    assert np.linalg.norm(sw.pos[0, 0] - sw.pos[0, 1]) > r2 - 1e-6
+    np.testing.assert_allclose((sw.vel[0, 0] + sw.vel[0, 1])[2], -1.5, atol=1e-6)
+    # (c) a glancing pass outside the threshold leaves both untouched; with pair_contact = 0 (a) passes straight through
+    sw = _two(_p(**base), [[-0.5, 0.0, 2], [0.5, r2 + 0.03, 2]], [[1, 0, 0], [-1, 0, 0]])
+    for _ in range(100):
+        sw.step(None, None)
+    np.testing.assert_allclose(sw.vel[0], [[1, 0, 0], [-1, 0, 0]], atol=1e-12)
+    sw = _two(_p(pair_contact=0, **base), [[-0.5, 0, 2], [0.5, 0, 2]], [[1, 0, 0], [-1, 0, 0]])
+    for _ in range(100):
+        sw.step(None, None)
+    assert sw.pos[0, 0, 0] > sw.pos[0, 1, 0]
+    # (d) an overlap is pushed out with erp, not ejected: two spheres 2 cm inside each other, at rest
+    sw = _two(_p(**base), [[0, 0, 2], [r2 - 0.02, 0, 2]], [[0, 0, 0], [0, 0, 0]])
+    sw.step(None, None)
+    np.testing.assert_allclose(sw.vel[0, 1, 0] - sw.vel[0, 0, 0], 0.02 * 0.2 / 0.01, rtol=1e-5)   # pen * erp / dt

@@ -26,6 +26,9 @@ if os.environ.get("NOCONTACT"):     # what the step costs without the ground: no
 if os.environ.get("SOLVER_ITERS"):  # what the step would cost if the contact sweeps stopped after this many (the run's physics changes)
     prm = mrsgym_amd.default_params(); prm.solver_iters = int(os.environ["SOLVER_ITERS"])
     sh.set_params(prm)
+if os.environ.get("PAIR") == "0":    # without quad-quad contact (MrsParams.pair_contact)
+    prm = mrsgym_amd.default_params(); prm.pair_contact = 0
+    sh.set_params(prm)
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
 acts = ActionStream(ATYPE, E, N, pos, seed=1000)
 table = [torch.from_numpy(acts(50 * k)).cuda() for k in range((ROLLIN + K * REPS) // 50 + 2)]
