@@ -637,3 +637,25 @@ def test_round_euler_readback_kwarg_reaches_the_kernel():
         w[flag] = env.shard.view(env.shard.angvel).clone()
     d = float((w[True] - w[False]).abs().max())
     assert 0.0 < d < 1e-6, d
+
+
+def test_quad_contact_kwarg_reaches_the_kernel():
+    """MRS(..., QUAD_CONTACT=...) -> MrsParams.pair_contact: two quadcopters on a head-on course in
+    free flight bounce off each other's spheres with it, and pass through each other without."""
+    import mrsgym_amd
+    pos = torch.tensor([[[0.0, 0.0, 20.0], [0.6, 0.0, 20.0]]])
+    sep = {}
+    for flag in (True, False):
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=1, N_AGENTS=2, state_fn=state_fn, START_POS=pos, ACTION_TYPE="set_target_vel",
+                              QUAD_CONTACT=flag)
+        assert int(env.shard.params.pair_contact) == int(flag)
+        env.reset(vel=torch.tensor([[[1.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]]))
+        a = torch.tensor([[[1.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]]).cuda()
+        m = []
+        for _ in range(40):
+            env.step(a)
+            p = env.shard.view(env.shard.pos)[0]
+            m.append(float(p[1, 0] - p[0, 0]))
+        sep[flag] = min(m)
+    assert sep[True] > 0.12 - 1e-4, sep          # spheres of radius 0.06 never overlap by more than the solver's slop
+    assert sep[False] < 0.0, sep                 # without it the two swap sides
