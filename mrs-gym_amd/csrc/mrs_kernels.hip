@@ -544,6 +544,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
 #define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
     if (tl && (tid & 63) == 0) tl[11] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF); // wave start on the 100 MHz chip-wide clock
+    if (tl && (tid & 63) == 0) { // where the wave runs: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID (tools/timeline_simd.py)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tl[13] = (float)(hw & 0xFFFF); tl[14] = (float)(hw >> 16); tl[15] = (float)(xcc & 0xF);
+    }
 #elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/isa_sections.py)
 #define TL(k) asm volatile("; MRS_MARK " #k)
 #else
