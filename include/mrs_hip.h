@@ -85,7 +85,10 @@ typedef struct MrsParams {
     int32_t round_euler_readback;
     /* 1 (default): quad-quad contact -- every quadcopter a sphere of coll_radius; a pair within contact_threshold gets,
      * per body, half of the normal velocity change that closes the gap this step / pushes the overlap out with erp (one
-     * pass, no friction, no torque; the build's own model).  Needs enable_contact. */
+     * pass, no friction, no torque; the build's own model).  Needs enable_contact.  The step finds the
+     * envs that have such a pair from flags its adjacency pass left for the positions it wrote: a caller that writes
+     * MrsBuffers.pos itself rather than through mrs_set_state* / mrs_spawn* calls mrs_observe or mrs_adjacency afterwards
+     * (either refreshes the flags), or the first step after the write may miss a new contact. */
     int32_t pair_contact;
     int32_t reserved1;
 } MrsParams;

@@ -1818,12 +1818,23 @@ static int launch_set(MrsHandle *, const SetArgs &S, hipStream_t st)
     return e == hipSuccess ? 0 : hipfail(e, "mrs_set_state launch");
 }
 
-// Positions were rewritten from outside the step (set_state, spawn): every env looks for quad-quad contact partners in its
-// next step (StepArgs.pair_flag); the adjacency pass of that step -- or of mrs_observe / mrs_adjacency -- makes the flags exact again.
-static int pairs_unknown(MrsHandle *h, hipStream_t st, const char *where)
+// Positions were rewritten from outside the step (set_state, spawn): the envs concerned (all, or those of env_mask) look
+// for quad-quad contact partners in their next step (StepArgs.pair_flag); the adjacency pass of that step -- or of
+// mrs_observe / mrs_adjacency -- makes the flags exact again.  (Per env, so that a loop that resets a few envs every step
+// -- MRS(AUTO_RESET=True) -- does not send the whole swarm through the scan.)
+__global__ void k_pairs_unknown(int *flag, const uint8_t *mask, int E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E && mask[e]) flag[e] = 1;
+}
+static int pairs_unknown(MrsHandle *h, const uint8_t *env_mask, hipStream_t st, const char *where)
 {
     if (!h->pair_flag) return 0;
-    hipError_t e = hipMemsetAsync(h->pair_flag, 1, (size_t)h->E * sizeof(int), st);
+    hipError_t e;
+    if (env_mask) {
+        hipLaunchKernelGGL(k_pairs_unknown, dim3((unsigned)((h->E + 255) / 256)), dim3(256), 0, st, h->pair_flag, env_mask, h->E);
+        e = hipGetLastError();
+    } else e = hipMemsetAsync(h->pair_flag, 1, (size_t)h->E * sizeof(int), st);
     return e == hipSuccess ? 0 : hipfail(e, where);
 }
 
@@ -1838,7 +1849,7 @@ extern "C" int mrs_set_state(MrsHandle *h, const MrsBuffers *b, const float *pos
     S.b = *b; S.pos = pos; S.ori = ori; S.vel = vel; S.angvel = angvel; S.mask = env_mask; S.ori_kind = ori_kind;
     S.N = h->N; S.T = (size_t)h->E * h->N;
     const int rc = launch_set(h, S, (hipStream_t)stream);
-    return rc ? rc : pairs_unknown(h, (hipStream_t)stream, "mrs_set_state");
+    return rc ? rc : pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_set_state");
 }
 
 extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, const double *quat,
@@ -1851,7 +1862,7 @@ extern "C" int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double
     S.b = *b; S.pos64 = pos; S.quat64 = quat; S.vel64 = vel; S.angvel64 = angvel; S.mask = env_mask;
     S.N = h->N; S.T = (size_t)h->E * h->N;
     const int rc = launch_set(h, S, (hipStream_t)stream);
-    return rc ? rc : pairs_unknown(h, (hipStream_t)stream, "mrs_set_state_f64");
+    return rc ? rc : pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_set_state_f64");
 }
 
 extern "C" int mrs_pid_reset(MrsHandle *h, const MrsBuffers *b, const uint8_t *env_mask, void *stream)
@@ -1893,7 +1904,7 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
     const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? pairs_unknown(h, (hipStream_t)stream, "mrs_spawn") : hipfail(e, "mrs_spawn launch");
+    return e == hipSuccess ? pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_spawn") : hipfail(e, "mrs_spawn launch");
 }
 
 extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *candidates, int n_rounds, int resume, double agent_radius,
@@ -1910,7 +1921,7 @@ extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *ca
     const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? pairs_unknown(h, (hipStream_t)stream, "mrs_spawn_from") : hipfail(e, "mrs_spawn_from launch");
+    return e == hipSuccess ? pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_spawn_from") : hipfail(e, "mrs_spawn_from launch");
 }
 
 // ---------------------------------------------------------------------------------------------------- sensors

@@ -640,22 +640,18 @@ def test_round_euler_readback_kwarg_reaches_the_kernel():
 
 
 def test_quad_contact_kwarg_reaches_the_kernel():
-    """MRS(..., QUAD_CONTACT=...) -> MrsParams.pair_contact: two quadcopters on a head-on course in
-    free flight bounce off each other's spheres with it, and pass through each other without."""
+    """MRS(..., QUAD_CONTACT=...) -> MrsParams.pair_contact: two quadcopters 0.13 m apart (inside the
+    contact range 2 r + threshold = 0.14) closing at 3 m/s lose, in one step, the part of the closing velocity that would
+    take them past touching (gap / dt = 1 m/s stays) -- 1 m/s each -- with it, and nothing without."""
     import mrsgym_amd
-    pos = torch.tensor([[[0.0, 0.0, 20.0], [0.6, 0.0, 20.0]]])
-    sep = {}
+    pos = torch.tensor([[[0.0, 0.0, 20.0], [0.13, 0.0, 20.0]]])
+    vx = {}
     for flag in (True, False):
         env = mrsgym_amd.make('mrs-v0', N_ENVS=1, N_AGENTS=2, state_fn=state_fn, START_POS=pos, ACTION_TYPE="set_target_vel",
                               QUAD_CONTACT=flag)
         assert int(env.shard.params.pair_contact) == int(flag)
         env.reset(vel=torch.tensor([[[1.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]]))
-        a = torch.tensor([[[1.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]]).cuda()
-        m = []
-        for _ in range(40):
-            env.step(a)
-            p = env.shard.view(env.shard.pos)[0]
-            m.append(float(p[1, 0] - p[0, 0]))
-        sep[flag] = min(m)
-    assert sep[True] > 0.12 - 1e-4, sep          # spheres of radius 0.06 never overlap by more than the solver's slop
-    assert sep[False] < 0.0, sep                 # without it the two swap sides
+        env.step(torch.tensor([[[1.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]]).cuda())
+        vx[flag] = env.shard.view(env.shard.vel)[0, :, 0].cpu().numpy()
+    assert abs(vx[False][0] - 1.5) < 0.05 and abs(vx[False][1] + 1.5) < 0.05, vx
+    assert abs(vx[True][0] - 0.5) < 0.05 and abs(vx[True][1] + 0.5) < 0.05, vx

@@ -567,3 +567,33 @@ def test_quad_quad_single_pair_of_an_env():
         assert sw.vel[e, a, 0] < 1.0 and sw.vel[e, b, 0] > -1.0, (e, sw.vel[e, a], sw.vel[e, b])   # they did collide
         assert np.linalg.norm(sw.pos[e, a] - sw.pos[e, b]) > 0.12 - 1e-5
     assert sw.vel[E - 1, 7, 0] < 1.0 and sw.vel[E - 1, 50, 0] < 1.0
+
+
+def test_quad_quad_contact_after_a_masked_set_state():
+    """mrs_set_state with an env mask marks only those envs "look everywhere" (k_pairs_unknown); the others keep the flags
+    their last adjacency pass left.  Env 1 is re-placed onto a collision course in the middle of a rollout in which env 0
+    is about to collide and env 2 never does: all three follow the oracle."""
+    import mrsgym_amd
+    E, N = 3, 64
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 2) * 3.0
+    pos = np.zeros((E, N, 3), np.float32); vel = np.zeros((E, N, 3), np.float32)
+    pos[..., :2] = g; pos[..., 2] = 50.0
+    pos[0, 4] = [100, 100, 60]; pos[0, 44] = [100.7, 100.02, 60.0]; vel[0, 4] = [1.5, 0, 0]; vel[0, 44] = [-1.5, 0, 0]
+    eul = np.zeros((E, N, 3), np.float32); z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.set_state(pos=pos, ori=eul, vel=vel, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=4)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=vel.astype(np.float64), angvel=z.astype(np.float64))
+    for t in range(70):
+        if t == 10:                                 # env 1 only: two agents 0.15 m apart, closing at 1 m/s -> in range at once
+            g_ = _gpu_state(sh)
+            p2 = g_["pos"].astype(np.float32); v2 = g_["vel"].astype(np.float32)
+            p2[1, 9] = [100, 100, 60]; p2[1, 30] = [100.15, 100.0, 60.0]; v2[1, 9] = [0.5, 0, 0]; v2[1, 30] = [-0.5, 0, 0]
+            sh.set_state(pos=p2, vel=v2, env_mask=np.array([0, 1, 0], np.uint8))
+            sw.pos[1] = p2[1].astype(np.float64); sw.vel[1] = v2[1].astype(np.float64)
+        sh.step(None, None)
+        sw.step(None, None)
+        g_ = _gpu_state(sh)
+        assert np.abs(g_["pos"] - sw.pos).max() < 2e-6 and np.abs(g_["vel"] - sw.vel).max() < 2e-5, t
+    assert sw.vel[1, 9, 0] < 0.4 and sw.vel[0, 4, 0] < 1.0                      # both pairs met
+    assert np.linalg.norm(sw.pos[1, 9] - sw.pos[1, 30]) > 0.12 - 1e-5
