@@ -323,9 +323,9 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             uint32_t hm = 0; // neighbours k = 1..31 within quad-quad contact range, bit k; the antipode k = 32 in `ht`
             bool ht = false;
             // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
-            // (unless the contact flag wants the distances)
-            if (!comm_inf || want_hit) {
-                const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
+            // (unless the contact flag wants the distances: the second loop)
+            const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
+            if (!comm_inf) {
                 // (consuming the handed-over verdicts one pass late, as the downwash loop does with its terms, was measured:
                 // no gain, 26.3 against 26.3 us per step)
                 auto verdict = [&](int k, float d2) {
@@ -349,6 +349,15 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                     verdict(31, d2.x);
                     top = d2.y <= thr ? 1u : 0u;
                     ht = d2.y <= rc2;
+                }
+            } else if (want_hit) { // no rows wanted (RETURN_A = False) or all ones: the contact range only, nothing to hand over
+#pragma unroll
+                for (int k = 1; k < 33; k += 2) {
+                    f2 rx, ry, rz;
+                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                    hm |= d2.x <= rc2 ? (1u << k) : 0u;
+                    if (k + 1 < 32) hm |= d2.y <= rc2 ? (2u << k) : 0u; else ht = d2.y <= rc2;
                 }
             }
             if (want_hit) { // the wave is the env; every unordered pair was tested once (the antipodes by both ends)
