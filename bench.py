@@ -23,6 +23,7 @@ SURVEY.md 8d: 268 B per agent-step at this config); `cpu_baseline` times the CPU
 the reference's algorithm, OpenMP over envs) on a bounded sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -213,6 +214,10 @@ def main():
     # the torch kernels of rollin()'s grounded-share expression are loaded here, not at their first use between roll-in and
     # warm-up (a code-object load is ~55 ms of host time with the GPU idle: kernel trace, tools/trace_bench.sh)
     float((env.shard.pos[2] < 0.6).float().mean())
+    # no collector pause between here and the end of the timed region (in its 20-step form, 0.5 ms, one pause would be a
+    # tenth of it); collected now, while the GPU has nothing queued, not between roll-in and warm-up
+    gc.collect()
+    gc.disable()
     warm(prewarm_s)
     grounded = rollin(env)
     agent_steps = float(E) * N * args.steps * world

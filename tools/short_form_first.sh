@@ -1,0 +1,3 @@
+#!/bin/bash
+# the driver's form of the bench as the FIRST process on a fresh box, then twice more
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dense-a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"run\", sys.argv[1], \"%.4g\" % d[\"value\"], \"ms/step %.2f\" % (d[\"ms_per_step\"]*1e3), \"kernel %.2f\" % (d[\"roofline\"][\"kernel_ms\"]*1e3), \"host %.2f\" % (d[\"host_ms_per_step\"]*1e3))" $i; done
