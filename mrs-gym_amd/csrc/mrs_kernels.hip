@@ -41,6 +41,7 @@ struct StepArgs {
     // quad-quad contact (MrsParams.pair_contact, mrs_device.hpp pair_contact_term): an env's flag says that the adjacency
     // pass over the positions it is starting from saw a pair within contact range; only flagged envs look for partners
     int *pair_flag;     // [E] library workspace, or null when the model is off
+    unsigned long long *pair_rows; // [T][W] library workspace: who is within contact range of whom (valid where the flag says so)
     float pair_rc2;     // (2 r + contact_threshold)^2
     float pair_r2, pair_inv_dt, pair_erp_dt; // 2 r, 1 / dt, erp / dt
     Recips rc;
@@ -191,11 +192,13 @@ __device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
 // both come from five packed instructions, and each verdict lands at a compile-time bit position (one select and one
 // OR; the row's own bit is cleared once at the end).  Was: one float4 read, six scalar operations, two compares and a
 // 64-bit variable shift per agent -- 13 vector instructions per pair against 6 (N = 256: 68 -> see DESIGN.md section 6).
-__device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row)
+__device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row,
+                                              unsigned long long *hrow)
 {
-    // returns whether another agent of the env is within quad-quad contact range (A.pair_rc2; coincident centres excluded)
+    // returns whether another agent of the env is within quad-quad contact range (A.pair_rc2), and notes which in hrow
+    // (same bit layout as row; null when the contact model is off)
     bool hit = false;
-    const bool want_hit = A.pair_flag != nullptr;
+    const bool want_hit = hrow != nullptr;
     float rc2 = A.pair_rc2;
     asm volatile("" : "+v"(rc2));
     float thr = thr_s;
@@ -204,23 +207,23 @@ __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, co
     const f2 mx = splat(me.x), my = splat(me.y), mz = splat(me.z);
     for (int wd = 0; wd < A.W; ++wd) {
         const int j0 = wd * 64, jn = min(64, A.N - j0);
-        uint32_t half[2] = {0u, 0u};
+        uint32_t half[2] = {0u, 0u}, hhalf[2] = {0u, 0u};
         if (inf && !want_hit) {
             const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
             half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
         } else if (jn == 64) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                uint32_t bits = 0;
+                uint32_t bits = 0, hb = 0;
 #pragma unroll
                 for (int jj = 0; jj < 32; jj += 2) {
                     const int j = j0 + hh * 32 + jj;
                     const f2 dx = pk_sub(mx, f2{tx[j], tx[j + 1]}), dy = pk_sub(my, f2{ty[j], ty[j + 1]}), dz = pk_sub(mz, f2{tz[j], tz[j + 1]});
                     const f2 d2 = pk_fma(dz, dz, pk_fma(dy, dy, pk_mul(dx, dx)));
                     bits |= (d2.x <= thr ? (1u << jj) : 0u) | (d2.y <= thr ? (2u << jj) : 0u);
-                    hit |= (d2.x <= rc2 && d2.x > 0.f) || (d2.y <= rc2 && d2.y > 0.f);
+                    hb |= (d2.x <= rc2 ? (1u << jj) : 0u) | (d2.y <= rc2 ? (2u << jj) : 0u);
                 }
-                half[hh] = bits;
+                half[hh] = bits; hhalf[hh] = hb;
             }
         } else { // the last, partial word of an N that is not a multiple of 64
             for (int jj = 0; jj < jn; ++jj) {
@@ -228,18 +231,19 @@ __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, co
                 const float dx = f32sub(me.x, tx[j]), dy = f32sub(me.y, ty[j]), dz = f32sub(me.z, tz[j]);
                 const float d2 = f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx)));
                 if (d2 <= thr) half[jj >> 5] |= 1u << (jj & 31);
-                hit |= d2 <= rc2 && d2 > 0.f;
+                if (d2 <= rc2) hhalf[jj >> 5] |= 1u << (jj & 31);
             }
         }
         if (inf) { // ones - eye whatever the positions are (the loops above ran for the contact range only)
             const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
             half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
         }
-        uint64_t bits = ((uint64_t)half[1] << 32) | half[0];
-        if ((unsigned)(i - j0) < 64u) bits &= ~(1ull << (i - j0)); // ones - eye (MRS.py:118-119, :123)
+        uint64_t bits = ((uint64_t)half[1] << 32) | half[0], hbits = ((uint64_t)hhalf[1] << 32) | hhalf[0];
+        if ((unsigned)(i - j0) < 64u) { bits &= ~(1ull << (i - j0)); hbits &= ~(1ull << (i - j0)); } // ones - eye (MRS.py:118-119, :123)
         if (row) row[wd] = bits;
+        if (want_hit) { hrow[wd] = hbits; hit |= hbits != 0; }
     }
-    return hit && want_hit;
+    return hit;
 }
 
 
@@ -277,6 +281,10 @@ __device__ __forceinline__ void tile64_rel2(const float *t, int k, f2 mx, f2 my,
 // its env (63 neighbours per lane, alone on its SIMD by then) lengthened every launch by ~1.5 us; with the pair named it
 // evaluates one term.  (Not a bit of 0x01010101, the "unknown" pattern that hipMemset(.., 1, ..) leaves.)
 #define MRS_PAIR_SINGLE 0x40000000
+// several pairs: StepArgs.pair_rows holds, for every agent of the env, the agents within contact range of it (bit j of word
+// j / 64), written by the same adjacency pass.  Any other non-zero value (1, the memset pattern): unknown, the step looks
+// at every pair of the env.
+#define MRS_PAIR_ROWS 2
 
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
@@ -365,7 +373,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                 const uint64_t testers = __builtin_amdgcn_ballot_w64(cnt != 0);
                 int flag = 0;
                 if (testers != 0) { // rare (a fraction of a percent of the envs of the benchmark rollout)
-                    flag = 1; // several pairs: the step scans the env
+                    flag = MRS_PAIR_ROWS; // several pairs: every lane notes its partners (below)
                     const int a = __builtin_ctzll(testers), nb = __builtin_popcountll(testers);
                     if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
                         const uint32_t hma = (uint32_t)__builtin_amdgcn_readlane((int)hm, a);
@@ -374,6 +382,15 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                         } else if (nb == 2 && a < 32 && __builtin_amdgcn_ballot_w64(ht && hm == 0) == testers && (testers >> (a + 32)) == 1ull) {
                             flag = MRS_PAIR_SINGLE | a | ((a + 32) << 8);
                         }
+                    }
+                    if (flag == MRS_PAIR_ROWS) {
+                        // the partners of a lane: the ones it tested itself (hm, relative bit k) and the ones that tested it
+                        // (handed over as in the loop above, mirrored into relative bit 64-k), rotated into absolute columns
+                        uint32_t hrh = 0;
+#pragma unroll
+                        for (int k = 1; k < 32; ++k) hrh |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)(hm & (1u << k)));
+                        const uint64_t hrel = ((uint64_t)((__builtin_bitreverse32(hrh) << 1) | (ht ? 1u : 0u)) << 32) | hm;
+                        A.pair_rows[(size_t)e * 64 + lane] = lane ? ((hrel << lane) | (hrel >> (64 - lane))) : hrel;
                     }
                 }
                 if (lane == 0) A.pair_flag[e] = flag;
@@ -384,11 +401,12 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
         }
     } else {
         bool hit = false;
-        if (live) hit = adjacency_row(A, thr_s, gx + el * A.N, gx + BLOCK + el * A.N, gx + 2 * BLOCK + el * A.N, i, mine, row);
+        if (live) hit = adjacency_row(A, thr_s, gx + el * A.N, gx + BLOCK + el * A.N, gx + 2 * BLOCK + el * A.N, i, mine, row,
+                                      want_hit ? A.pair_rows + ((size_t)e * A.N + i) * A.W : nullptr);
         if (want_hit) { // workgroup-uniform: every thread takes the barrier
             if (hit) atomicOr(&hit_flag[el], 1);
             __syncthreads();
-            if (live && i == 0) A.pair_flag[e] = hit_flag[el];
+            if (live && i == 0) A.pair_flag[e] = hit_flag[el] ? MRS_PAIR_ROWS : 0; // every lane of the env has written its row
         }
     }
 }
@@ -945,14 +963,26 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                                       f32sub(vx, t64[64 + j]), f32sub(vy, t64[192 + j]), f32sub(vz, t64[320 + j]), dv);
                 }
             } else if (mine) {
-                for (int jj = 1; jj < AN; ++jj) {
-                    int j = i + jj;
-                    j = j >= AN ? j - AN : j;
+                // the terms of a lane are added in ascending order of the partner's index, as the oracle's loop does
+                auto partner = [&](int j) {
                     float qx, qy, qz, wx, wy, wz;
                     if (tile_soa) { qx = t64[j]; qy = t64[128 + j]; qz = t64[256 + j]; wx = t64[64 + j]; wy = t64[192 + j]; wz = t64[320 + j]; }
                     else if (ring) { qx = ring_x[j]; qy = ring_x[2 * AN + j]; qz = ring_x[4 * AN + j]; wx = ring_x[AN + j]; wy = ring_x[3 * AN + j]; wz = ring_x[5 * AN + j]; }
                     else { const float4 a = lds_tile[el * AN + j], b = lds_tile[BLOCK + el * AN + j]; qx = a.x; qy = a.y; qz = a.z; wx = b.x; wy = b.y; wz = b.z; }
                     pair_contact_term(A, f32sub(px, qx), f32sub(py, qy), f32sub(pz, qz), f32sub(vx, wx), f32sub(vy, wy), f32sub(vz, wz), dv);
+                };
+                if (pf == MRS_PAIR_ROWS) { // the adjacency pass noted every agent's partners: one term per set bit
+                    const unsigned long long *rw = A.pair_rows + (wb_base + la) * (size_t)AW;
+                    for (int wd = 0; wd < AW; ++wd) {
+                        unsigned long long bits = rw[wd];
+                        while (bits) {
+                            partner(wd * 64 + __builtin_ctzll(bits));
+                            bits &= bits - 1;
+                        }
+                    }
+                } else { // positions set from outside since the last adjacency pass: every other agent of the env
+                    for (int j = 0; j < AN; ++j)
+                        if (j != i) partner(j);
                 }
             }
             v[0] += (double)dv[0]; v[1] += (double)dv[1]; v[2] += (double)dv[2];
@@ -1424,6 +1454,7 @@ struct MrsHandle {
     bool fused;         // one-launch step (256-thread workgroups; MRS_STEP_SPLIT=1 keeps the three-launch form)
     unsigned step_parity;
     int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
+    unsigned long long *pair_rows; // device workspace [T][W]: the candidates per agent (StepArgs.pair_rows)
     float4 *eul_key;    // device workspace, fused step: Euler angles carried from a step's observation slice to the next
     double *eul_ang;    //   step's attitude controller (see MRS_EUL_CARRY): float32 quaternion key [T], float64 angles [3][T]
 };
@@ -1577,9 +1608,10 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
-    h->eul_key = nullptr; h->eul_ang = nullptr; h->pair_flag = nullptr;
+    h->eul_key = nullptr; h->eul_ang = nullptr; h->pair_flag = nullptr; h->pair_rows = nullptr;
     if (e == hipSuccess) {
         e = hipMalloc((void **)&h->pair_flag, (size_t)n_envs * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->pair_rows, (size_t)n_envs * n_agents * (size_t)((n_agents + 63) / 64) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->pair_flag, 1, (size_t)n_envs * sizeof(int)); // nothing known yet: every env looks
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
@@ -1596,6 +1628,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (h->eul_key) (void)hipFree(h->eul_key);
         if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->pair_flag) (void)hipFree(h->pair_flag);
+        if (h->pair_rows) (void)hipFree(h->pair_rows);
         (void)hipSetDevice(cur);
         delete h;
         return hipfail(e, "mrs_create workspace");
@@ -1608,9 +1641,10 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
-    if (h->ws || h->cs || h->eul_key || h->eul_ang || h->pair_flag) {
+    if (h->ws || h->cs || h->eul_key || h->eul_ang || h->pair_flag || h->pair_rows) {
         DeviceGuard dg(h->device);
         if (h->pair_flag) (void)hipFree(h->pair_flag);
+        if (h->pair_rows) (void)hipFree(h->pair_rows);
         if (h->eul_key) (void)hipFree(h->eul_key);
         if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->ws) (void)hipFree(h->ws);
@@ -1636,6 +1670,7 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
     A.park_z = h->P.ground_z + std::sqrt(h->P.coll_radius * h->P.coll_radius + h->P.coll_half_len * h->P.coll_half_len) + h->P.contact_threshold;
     A.pair_flag = (h->P.enable_contact && h->P.pair_contact && h->N > 1) ? h->pair_flag : nullptr;
+    A.pair_rows = h->pair_rows;
     A.pair_r2 = 2.0f * (float)h->P.coll_radius;
     A.pair_rc2 = (A.pair_r2 + (float)h->P.contact_threshold) * (A.pair_r2 + (float)h->P.contact_threshold);
     A.pair_inv_dt = (float)(1.0 / h->P.dt); A.pair_erp_dt = (float)(h->P.erp / h->P.dt);

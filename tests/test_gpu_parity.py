@@ -597,3 +597,41 @@ def test_quad_quad_contact_after_a_masked_set_state():
         assert np.abs(g_["pos"] - sw.pos).max() < 2e-6 and np.abs(g_["vel"] - sw.vel).max() < 2e-5, t
     assert sw.vel[1, 9, 0] < 0.4 and sw.vel[0, 4, 0] < 1.0                      # both pairs met
     assert np.linalg.norm(sw.pos[1, 9] - sw.pos[1, 30]) > 0.12 - 1e-5
+
+
+@pytest.mark.parametrize("E,N", [(3, 64), (4, 12), (2, 130), (2, 300)])
+def test_quad_quad_several_partners_at_once(E, N):
+    """An agent squeezed between two others (and a cluster of four) has several contacts in the same step: the adjacency
+    pass notes every agent's partners (MRS_PAIR_ROWS, StepArgs.pair_rows) and the step adds one term per partner, in
+    ascending order of the partner's index like the oracle's loop -- the float32 sums must agree to the last bits the
+    velocity exchange leaves (2e-6).  Indices chosen so that partners sit below and above the agent, in other waves
+    (N > 64) and in another adjacency word (N > 64)."""
+    import mrsgym_amd
+    rng = np.random.default_rng(100 + N)
+    side = int(np.ceil(np.sqrt(N)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:N] * 3.0
+    pos = np.zeros((E, N, 3), np.float32); vel = np.zeros((E, N, 3), np.float32)
+    pos[..., :2] = g; pos[..., 2] = 50.0 + rng.uniform(0, 1, (E, N))
+    mid, lo, hi = N // 2, 2, N - 1
+    for e in range(E):
+        pos[e, lo] = [100.0, 100, 60]; pos[e, mid] = [100.45, 100.01, 60.0 + 0.01 * e]; pos[e, hi] = [100.9, 100.0, 60.01]
+        vel[e, lo] = [1.5, 0, 0]; vel[e, mid] = [0, 0, 0]; vel[e, hi] = [-1.5, 0, 0]          # the middle one is hit from both sides
+        c = [0, 5, N - 3, (N // 3) | 1]                                                       # four closing on one point
+        for k, a in enumerate(c):
+            ang = 2 * np.pi * k / 4 + 0.1
+            pos[e, a] = [200 + 0.3 * np.cos(ang), 200 + 0.3 * np.sin(ang), 60 + 0.005 * k]
+            vel[e, a] = [-1.2 * np.cos(ang), -1.2 * np.sin(ang), 0]
+    eul = np.zeros((E, N, 3), np.float32); z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.set_state(pos=pos, ori=eul, vel=vel, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=vel.astype(np.float64), angvel=z.astype(np.float64))
+    two = False
+    for t in range(60):
+        d = np.linalg.norm(sw.pos[:, mid, None] - sw.pos[:, [lo, hi]], axis=-1)
+        two |= bool((d < 0.14).all(-1).any())                            # both neighbours of the middle one in range at once
+        sh.step(None, None)
+        sw.step(None, None)
+        g_ = _gpu_state(sh)
+        assert np.abs(g_["pos"] - sw.pos).max() < 2e-6 and np.abs(g_["vel"] - sw.vel).max() < 2e-5, t
+    assert two
