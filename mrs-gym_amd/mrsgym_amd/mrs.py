@@ -259,15 +259,67 @@ class MRS(_EnvBase):
             if nt > 8:
                 torch.set_num_threads(nt)
 
+    @staticmethod
+    def _dist_to(d, dev):
+        """The same distribution with its parameter tensors on `dev` (torch.distributions has no .to()): util.CombinedDistribution
+        and TransformedDistribution recursively, any torch Distribution through its arg_constraints.  Raises for what it
+        cannot rebuild; a transform that keeps tensors of its own fails at the first sample instead -- both are caught by
+        _spawn_user, which then samples on the host as before."""
+        from torch.distributions import Distribution, TransformedDistribution
+        from .util import CombinedDistribution
+        if isinstance(d, CombinedDistribution):
+            return CombinedDistribution([MRS._dist_to(x, dev) for x in d.dist], mixer=d.mixer, dim=d.dim)
+        if isinstance(d, TransformedDistribution):
+            return TransformedDistribution(MRS._dist_to(d.base_dist, dev), list(d.transforms))
+        if isinstance(d, Distribution) and d.arg_constraints:
+            args = {k: getattr(d, k) for k in d.arg_constraints if k in d.__dict__}
+            if not args:
+                raise TypeError("no parameters found")
+            return type(d)(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in args.items()}, validate_args=False)
+        raise TypeError("cannot move %r to the device" % (type(d),))
+
+    def _start_pos_on_device(self):
+        """(distribution on the device or None, samples are per agent) for the current START_POS, looked at once per object."""
+        sp = self.START_POS
+        c = getattr(self, "_sp_cache", None)
+        if c is None or c[0] is not sp:
+            per_agent = sp.sample().dim() == 1      # (3,) per-agent samples vs (N,3) joint samples (MRS.py:129-132)
+            dev_dist = None
+            if self.device.type == "cuda":
+                try:
+                    dev_dist = self._dist_to(sp, self.device)
+                    x = dev_dist.sample((2,))
+                    if x.device.type != "cuda" or tuple(x.shape[1:]) != tuple(sp.sample().shape):
+                        dev_dist = None
+                except Exception:
+                    dev_dist = None
+            c = self._sp_cache = (sp, dev_dist, per_agent)
+        return c[1], c[2]
+
     def _spawn_user(self, env_mask=None, rounds=4):
         """MRS.generate_start_pos (MRS.py:127-154) for START_POS given as a distribution, for all (masked) envs at once:
-        the samples are drawn in bulk on the host (torch.distributions lives there) -- `rounds` re-sampling rounds per
-        env up front -- and the greedy rejection runs on the device (mrs_spawn_from).  Writes positions only."""
+        `rounds` re-sampling rounds per env are drawn up front and the greedy rejection runs on the device
+        (mrs_spawn_from).  The samples come from a copy of the distribution whose parameters live on the device when one
+        can be made (_dist_to: torch's own distributions, CombinedDistribution, TransformedDistribution) -- then for every
+        env, selected or not, with no host round trip (a loop that resets a few envs every step, AUTO_RESET, spends 0.7
+        instead of 7 ms per step that way: E = 512, N = 12, tools/profile_autoreset.py) -- and from the caller's own
+        object on the host otherwise, for the selected envs only.  Writes positions only."""
         sp, E, N, sh = self.START_POS, self.N_ENVS, self.N_AGENTS, self.shard
-        per_agent = sp.sample().dim() == 1          # (3,) per-agent samples vs (N,3) joint samples (MRS.py:129-132)
+        dev_dist, per_agent = self._start_pos_on_device()
         mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.bool).reshape(E)
         sh.status.bitwise_and_(~(native.STATUS_SPAWN_MORE | native.STATUS_SPAWN_FAIL))
         resume = False
+        for attempt in range(64 if dev_dist is not None else 0):
+            x = dev_dist.sample((E * rounds * N,) if per_agent else (E * rounds,)).reshape(E, rounds, N, 3)
+            sh.spawn_from(x.to(torch.float32), agent_radius=self.AGENT_RADIUS, env_mask=mask, resume=resume)
+            more = (sh.status & native.STATUS_SPAWN_MORE) != 0      # one host sync per attempt
+            if not bool(more.any()):
+                return
+            sh.status.bitwise_and_(~native.STATUS_SPAWN_MORE)
+            mask, resume, rounds = more, True, min(64, rounds * 2)
+        if dev_dist is not None:
+            raise RuntimeError("START_POS: no layout with all pairs >= 2*AGENT_RADIUS = %.2f m apart after many re-sampling "
+                               "rounds (the reference's generate_start_pos would still be looping, MRS.py:137-153)" % (2 * self.AGENT_RADIUS))
         for attempt in range(64):
             idx = torch.arange(E) if mask is None else torch.nonzero(mask.cpu()).flatten()
             if idx.numel() == 0:
@@ -399,8 +451,10 @@ class MRS(_EnvBase):
             if ori.dim() == 2 and E > 1:
                 ori = ori.unsqueeze(0).expand(E, N, ori.shape[-1])
         if not spawned:
-            self.shard.set_state(pos=pos, ori=ori, vel=torch.zeros(E, N, 3) if vel is None else vel,
-                                 angvel=torch.zeros(E, N, 3) if angvel is None else angvel, env_mask=mask)
+            z3 = getattr(self, "_zeros3", None)      # on the device already: a host tensor would be built and copied per call
+            if z3 is None:
+                z3 = self._zeros3 = torch.zeros(E, N, 3, dtype=torch.float32, device=self.device)
+            self.shard.set_state(pos=pos, ori=ori, vel=z3 if vel is None else vel, angvel=z3 if angvel is None else angvel, env_mask=mask)
         elif vel is not None or angvel is not None or ori is not None:
             self.shard.set_state(ori=ori, vel=vel, angvel=angvel, env_mask=mask)
         if self.RESET_CONTROLLERS:

@@ -115,6 +115,7 @@ def test_user_spawn_is_batched_on_the_device():
     assert float(d.min()) >= 0.6 - 1e-6 and float(p[..., 2].min()) >= 2 and float(p[..., 2].max()) <= 5
     assert float(p[..., :2].std()) > 1.0                                   # the Normal(0, 1.25) cloud, not a degenerate layout
     assert dt < 0.05, "reset() took %.1f ms" % (dt * 1e3)
+    assert env._sp_cache[1] is not None and env._sp_cache[1].dist[0].loc.is_cuda    # sampled on the device (MRS._dist_to)
     before = env.shard.view(env.shard.pos).clone()
     mask = torch.zeros(E, dtype=torch.bool); mask[::7] = True
     env.reset_envs(mask)
@@ -127,6 +128,18 @@ def test_user_spawn_is_batched_on_the_device():
     env2 = mrsgym_amd.make('mrs-v0', N_ENVS=64, N_AGENTS=N, state_fn=state_fn, START_POS=single)
     p2 = env2.get_Xk()[:, 0, :, :3]
     assert float((torch.cdist(p2, p2) + 10 * torch.eye(N, device=p2.device)).min()) >= 0.6 - 1e-6
+
+    class Opaque:                          # a caller's own sampler: nothing to rebuild on the device -> drawn on the host
+        def sample(self, shape=()):
+            return single.sample(shape)
+    env3 = mrsgym_amd.make('mrs-v0', N_ENVS=64, N_AGENTS=N, state_fn=state_fn, START_POS=Opaque())
+    assert env3._sp_cache[1] is None
+    m3 = torch.zeros(64, dtype=torch.bool); m3[5] = True
+    b3 = env3.shard.view(env3.shard.pos).clone()
+    env3.reset_envs(m3)
+    p3 = env3.shard.view(env3.shard.pos)
+    assert torch.equal(p3[~m3.cuda()], b3[~m3.cuda()]) and not torch.equal(p3[5], b3[5])
+    assert float((torch.cdist(p3.float(), p3.float()) + 10 * torch.eye(N, device=p3.device)).min()) >= 0.6 - 1e-6
 
 
 def test_callbacks_and_quirks():

@@ -154,3 +154,27 @@ def test_combined_distribution_batched_sampling():
             assert not a or a[0] == ()
             return torch.randn(3)
     assert MRS._draw(OneAtATime(), 6).shape == (6, 3)
+
+
+def test_distribution_rebuilt_on_another_device():
+    """MRS._dist_to: the START_POS distribution with its parameters on the device the swarm lives on (here 'cpu' stands in
+    for it) -- torch's own distributions, TransformedDistribution, util.CombinedDistribution -- samples with the same
+    shapes and the same support; what it cannot rebuild raises, and _spawn_user then samples the caller's object."""
+    import pytest, torch
+    from torch.distributions import Normal, Uniform, TransformedDistribution
+    from mrsgym_amd.util import CombinedDistribution, SphereTransform
+    from mrsgym_amd.mrs import MRS
+    N = 6
+    xy = TransformedDistribution(Normal(torch.zeros(N, 2), 1.0), [SphereTransform(radius=1.0, within=True)])
+    d = CombinedDistribution([xy, Uniform(1.0 * torch.ones(N, 1), 3.0 * torch.ones(N, 1))], mixer='cat', dim=1)
+    e = MRS._dist_to(d, torch.device("cpu"))
+    assert e is not d and e.dist[0].base_dist is not d.dist[0].base_dist
+    x = e.sample((50,))
+    assert x.shape == (50, N, 3) and float(x[..., 2].min()) >= 1 and float(x[..., 2].max()) <= 3
+    assert float(x[..., :2].norm(dim=-1).max()) <= 1 + 1e-6           # the transform travelled with it
+
+    class Opaque:
+        def sample(self, *a):
+            return torch.randn(3)
+    with pytest.raises(TypeError):
+        MRS._dist_to(Opaque(), torch.device("cpu"))
