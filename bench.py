@@ -166,8 +166,13 @@ def main():
         # stands between the last warm-up step and the first timed one
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(max(1, (args.steps - EV_SPAN) // EV_EVERY + 1))]
+        # the warm-up goes through what the timed steps go through, timing events included: on a fresh box the first
+        # hipEventRecord of a process runs library code that is not paged in yet
+        warm_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        warm_ev[0].record()
         for t in range(t_first, t_first + args.warmup):
             one_step(t)
+        warm_ev[1].record()
         if with_gather:
             gather.wait()
 
