@@ -243,7 +243,9 @@ def main():
     else:
         # `value`: BASELINE config 5 / north_star -- every step followed by the RCCL all-gather of the joint observation
         elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, True)
-        n_elapsed, _, _ = timed_region(env, args.rollin + total, False)
+        # the kernel's own duration for the roofline object comes from the region without the gather: with it the event
+        # spans on the step stream include the back-pressure waits for the side stream
+        n_elapsed, _, kernel_ms = timed_region(env, args.rollin + total, False)
         per_rank = E * N * 6 * 4
         extra["no_exchange"] = {"value": agent_steps / n_elapsed, "unit": "agent-steps/s", "ms_per_step": n_elapsed / args.steps * 1e3,
                                 "what": "the same K steps without the all-gather: step() itself has no exchange between shards"}
