@@ -73,8 +73,46 @@ def cpu_baseline(seconds=15.0):
         dt = time.perf_counter() - t0
         if dt > seconds or n >= 6000:
             break
-    return {"value": E * N_AGENTS * n / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+    return {"value": E * N_AGENTS * n / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port", "leg": "(b)",
             "sample": "%d envs x %d agents x %d steps of the same workload (C oracle, OpenMP over envs, %.1f s)" % (E, N_AGENTS, n, dt)}
+
+
+def literal_reference_leg():
+    """SURVEY.md 8d / BASELINE.md section 4, leg (a): the untouched reference needs `pybullet` and `gym` (setup.py:5) AND its
+    own source tree.  Probed, never installed or fetched; the reference tree does not travel to the GPU box, so even with
+    both importable this leg can only say so."""
+    missing = []
+    for mod in ("pybullet", "gym"):
+        try:
+            __import__(mod)
+        except Exception as e:                                   # ImportError, or a broken install
+            missing.append("%s (%s)" % (mod, type(e).__name__))
+    try:
+        import mrsgym  # noqa: F401  (an installed copy of the reference package, if the box happens to have one)
+        have_ref = True
+    except Exception:
+        have_ref = False
+    if missing or not have_ref:
+        return {"leg": "(a)", "status": "unavailable",
+                "why": "not importable on this box: " + ", ".join(missing + ([] if have_ref else ["mrsgym (the reference package itself)"]))}
+    # both importable and an installed mrsgym: time the README example (N=3) and N=64 x 1 env, 200 steps, one process
+    import time as _t
+    out = {"leg": "(a)", "status": "measured", "cores": 1}
+    try:
+        import gym
+        for n_agents, key in ((3, "n3"), (64, "n64")):
+            env = gym.make('mrs-v0', state_fn=lambda quad: torch.cat([quad.get_pos(), quad.get_vel()]), N_AGENTS=n_agents,
+                           ACTION_TYPE='set_target_vel', HEADLESS=True,
+                           **({} if n_agents <= 32 else {"START_POS": torch.from_numpy(__import__("util_scenarios").grid_spawn(1, n_agents)[0][0])}))
+            act = torch.zeros(n_agents, 3)
+            t0 = _t.perf_counter()
+            for _ in range(200):
+                env.step(act)
+            out[key + "_agent_steps_per_s_per_core"] = n_agents * 200 / (_t.perf_counter() - t0)
+            env.close()
+    except Exception as e:
+        out = {"leg": "(a)", "status": "unavailable", "why": "reference raised %s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def main():
@@ -249,8 +287,18 @@ def main():
         per_rank = E * N * 6 * 4
         extra["no_exchange"] = {"value": agent_steps / n_elapsed, "unit": "agent-steps/s", "ms_per_step": n_elapsed / args.steps * 1e3,
                                 "what": "the same K steps without the all-gather: step() itself has no exchange between shards"}
+        floor_ms = per_rank * (world - 1) / (min(world - 1, 7) * 76e9) * 1e3
+        one_gpu_step_ms = n_elapsed / args.steps * 1e3
         extra["obs_allgather"] = {"bytes_sent_per_rank_per_step": per_rank * (world - 1), "bytes_received_per_rank_per_step": per_rank * (world - 1),
-                                  "xgmi_floor_ms": per_rank * (world - 1) / (min(world - 1, 7) * 76e9) * 1e3,
+                                  "xgmi_floor_ms": floor_ms,
+                                  # what DESIGN.md section 8 predicts for this N from the link arithmetic alone, so that a measured line can be
+                                  # checked against it: the step hides under the gather once the gather is the longer of the two
+                                  "predicted": {"value": float(E) * N * world / (max(floor_ms, one_gpu_step_ms) * 1e-3),
+                                                "no_exchange": float(E) * N * world / (one_gpu_step_ms * 1e-3),
+                                                "xgmi_floor_ms": floor_ms,
+                                                "what": "value = E*N*world / max(xGMI floor, measured no-exchange step); at N = 8: 44 MB in per rank per step "
+                                                        "over 7 links x ~76 GB/s >= 83 us against a ~25 us step => ~2.5e10 agent-steps/s (~2.5x one GPU), "
+                                                        "no_exchange ~8x"},
                                   "what": "newest observation slice (E_local,N,6) float32 to every rank each step (RCCL, side stream, "
                                           "double-buffered); floor = bytes received / (links driven x ~76 GB/s per xGMI link direction)"}
     if rank != 0:
@@ -276,6 +324,10 @@ def main():
         "grounded_fraction_after_rollin": float(grounded), "ms_per_step": elapsed / args.steps * 1e3,
         "host_ms_per_step": host_elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "precision": "float64 rigid-body state, controller and force assembly (as Bullet / numpy in the reference); float32 where the "
+                     "reference is float32 (read-backs, downwash pair terms, adjacency distances) and, the build's own choice, in the "
+                     "ground-contact sweeps and the quad-quad contact terms (velocity changes added to the float64 state; tested against "
+                     "the float64 oracle at 1e-4 per step)",
         "config": {"workload": "N_AGENTS=64 x %d envs/GPU, ACTION_TYPE=set_target_vel (PID), RETURN_A=True COMM_RANGE=5.0, "
                                "K_HOPS=3, state_fn=cat(pos,vel), A %s%s" % (E, "dense fp32" if args.dense_a else "bit-packed",
                                                                              ", joint observation all-gathered every step" if world > 1 else ""),
@@ -292,7 +344,8 @@ def main():
         cb = cpu_baseline()
         # the literal reference cannot run here (pybullet absent); its Python controller alone
         # was measured at 305 us per agent-step on one core => an upper bound on what the reference itself could reach
-        cb["reference_python_bracket"] = {"us_per_agent_step_controller_only": 305.0, "agent_steps_per_s_per_core": 1e6 / 305.0,
+        cb["literal_reference"] = literal_reference_leg()
+        cb["reference_python_bracket"] = {"leg": "(c)", "us_per_agent_step_controller_only": 305.0, "agent_steps_per_s_per_core": 1e6 / 305.0,
                                           "agent_steps_per_s_all_cores": cb["cores"] * 1e6 / 305.0,
                                           "what": "kind (c) of SURVEY.md 8d: lower bound on the reference's cost (QuadControl Python only, "
                                                   "no Bullet, no downwash loop); the reference is single-threaded"}

@@ -152,7 +152,8 @@ int mrs_set_state_f64(MrsHandle *h, const MrsBuffers *b, const double *pos, cons
 int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
              const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream);
 
-/* n_substeps consecutive MRS.step calls in ONE launch (the `n_substeps` of SURVEY.md 8b; frame-skip / on-device rollouts):
+/* n_substeps consecutive MRS.step calls from ONE host call = n_substeps kernel launches queued back to back on the stream
+ * (the `n_substeps` of SURVEY.md 8b; frame-skip / on-device rollouts; an in-kernel substep loop was built and spills):
  * substep s uses the action batch at actions + s * action_stride (0: the same actions are held, as gym wrappers that
  * repeat an action do) and writes its observation slice at b->obs + s * obs_stride floats and its adjacency rows at
  * b->adj + s * adj_stride words (strides may be negative: a history ring that grows downwards).  Results are those of

@@ -786,6 +786,31 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwxy.x, dwxy.y, dwz};
 }
 
+// A body LYING FLAT AT REST on the ground (nine out of ten grounded bodies of a rollout: crashed quadcopters whose rotor
+// torques cancel) is the one case in which the sweeps of contact_solve_f32 have nothing to do: all four rim points are
+// active with the same gap and the same closing velocity, the equal-share start IS the solution (every point carries a
+// quarter of the impulse that stops the body, dv_z = max(rhs, 0)), the normal rows find rhs - dv_n = 0 and the friction
+// rows a tangential velocity of 0.  Evaluated here in the body's own lane: such a body is never listed for the solve.
+// "At rest": |R20|, |R21|, |w|, |v_xy| < 1e-9 and the common gap not within 1e-9 of the contact threshold -- the rim points'
+// gaps then differ by < 1.2e-10 m and their closing velocities by < 1.2e-10 m/s from the values used here, i.e. the result
+// is within ~3e-8 m/s of what the sweeps return (oracle/mrs_oracle.c:contact_solve has no such shortcut; the parity tests
+// compare the two).  Returns true when the body is dealt with (v updated, or no point within the threshold).
+MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, const double q[4], double v[3], const double w[3])
+{
+    const double eps = 1e-9;
+    // third row of btMatrix3x3::setRotation for a unit quaternion (|q|^2 - 1 ~ 1e-16 after every step's normalisation; a
+    // caller's own non-unit quaternion fails the tests below or changes the bound by its relative error)
+    const double r20 = 2.0 * (q[0] * q[2] - q[3] * q[1]), r21 = 2.0 * (q[1] * q[2] + q[3] * q[0]);
+    const double r22 = 1.0 - 2.0 * (q[0] * q[0] + q[1] * q[1]);
+    const double big = fmax(fmax(fmax(fabs(r20), fabs(r21)), fmax(fabs(w[0]), fabs(w[1]))), fmax(fmax(fabs(w[2]), fabs(v[0])), fabs(v[1])));
+    const double dist = (pz - P.ground_z) - P.coll_half_len * fabs(r22);
+    if (!(big < eps) || !(fabs(dist - P.contact_threshold) > eps)) return false;
+    if (dist > P.contact_threshold) return true; // flat and clear of the ground: no point within the threshold
+    const double rhs = -v[2] - dist * (dist > 0 ? K.inv_dt : P.erp * K.inv_dt);
+    v[2] += fmax(rhs, 0.0);
+    return true;
+}
+
 MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
 {
     const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);

@@ -21,6 +21,18 @@
 
 using namespace mrs;
 
+// Diagnostic knock-outs (tools/abl_build.sh "-DMRS_KO=<bits>"; results are WRONG, only the duration is looked at): what does
+// the launch cost without 1: the state stores of the tail, 2: the observation + adjacency stores, 4: the controller-memory
+// stores, 8: the downwash pair loop, 16: the adjacency pass.  The code stays (the store is taken iff E < 0).
+#ifndef MRS_KO
+#define MRS_KO 0
+#endif
+#if MRS_KO == -1 // chosen at run time through the environment variable MRS_KO, read by every mrs_step call (tools/steady_bench.py sets it after the roll-in)
+#define KO_KEEP(bit) (!(A.ko & (bit)))
+#else
+#define KO_KEEP(bit) (!(MRS_KO & (bit)) || A.E < 0)
+#endif
+
 // ------------------------------------------------------------------------------------------ args
 // Member order = order of first use.  The kernel reads its arguments through the scalar cache, which is cold when a
 // launch starts: every 64-byte line of this struct is a memory round trip that all waves of the launch wait for before
@@ -28,6 +40,9 @@ using namespace mrs;
 // constants (360 B, first needed by the controller) come last.
 struct StepArgs {
     int E, N, T, epb, D, W;
+#if MRS_KO == -1
+    int ko;
+#endif
     const float *actions;
     const uint8_t *mask;
     MrsBuffers b;
@@ -80,6 +95,19 @@ __device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_
     VELP(b.angvel)[a] = (vel_t)w[0]; VELP(b.angvel)[T + a] = (vel_t)w[1]; VELP(b.angvel)[2 * T + a] = (vel_t)w[2];
 }
 
+// Stores that leave the XCD's L2 at once (global_store ... sc1: agent-scope, write-through) instead of sitting there dirty
+// until the end-of-kernel release writes them back.  MRS_WT bits (A/B switch): 1 state planes, 2 observation + adjacency,
+// 4 controller memory.
+#ifndef MRS_WT
+#define MRS_WT 0
+#endif
+template <int BIT, class T>
+__device__ __forceinline__ void st(T *ptr, T v)
+{
+    if (MRS_WT & BIT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *ptr = v;
+}
+
 // Workgroup-relative addressing.  Agent a = wg_base + tid for every live lane of k_step / k_observe_adj, so a
 // plane access is (uniform pointer, SGPR pair) + (small 32-bit per-lane offset): the saddr form of global_load /
 // global_store, with the plane arithmetic on the scalar unit -- instead of one 64-bit VALU add per lane for
@@ -109,10 +137,10 @@ __device__ __forceinline__ void load_state(const WgBuffers &b, unsigned t, size_
 }
 __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size_t T, const double p[3], const double q[4], const double v[3], const double w[3])
 {
-    b.pos[t] = p[0]; (b.pos + T)[t] = p[1]; (b.pos + 2 * T)[t] = p[2];
-    b.quat[t] = q[0]; (b.quat + T)[t] = q[1]; (b.quat + 2 * T)[t] = q[2]; (b.quat + 3 * T)[t] = q[3];
-    b.vel[t] = (vel_t)v[0]; (b.vel + T)[t] = (vel_t)v[1]; (b.vel + 2 * T)[t] = (vel_t)v[2];
-    b.angvel[t] = (vel_t)w[0]; (b.angvel + T)[t] = (vel_t)w[1]; (b.angvel + 2 * T)[t] = (vel_t)w[2];
+    st<1>(b.pos + t, p[0]); st<1>(b.pos + T + t, p[1]); st<1>(b.pos + 2 * T + t, p[2]);
+    st<1>(b.quat + t, q[0]); st<1>(b.quat + T + t, q[1]); st<1>(b.quat + 2 * T + t, q[2]); st<1>(b.quat + 3 * T + t, q[3]);
+    st<1>(b.vel + t, (vel_t)v[0]); st<1>(b.vel + T + t, (vel_t)v[1]); st<1>(b.vel + 2 * T + t, (vel_t)v[2]);
+    st<1>(b.angvel + t, (vel_t)w[0]); st<1>(b.angvel + T + t, (vel_t)w[1]); st<1>(b.angvel + 2 * T + t, (vel_t)w[2]);
 }
 
 // The attitude controller of step t+1 reads the Euler angles of the state step t left behind (Quadcopter.py:54-61 ->
@@ -135,6 +163,12 @@ __device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, co
 {
     // state_fn = cat(pos, vel) (README.md:28-29, the bench's): the 24-byte row as three 8-byte stores instead of six
     if (n_obs == 2 && code == (MRS_OBS_POS | (MRS_OBS_VEL << 4)) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0 && !eul_key) {
+        if (MRS_WT & 2) {
+            unsigned long long *o8 = reinterpret_cast<unsigned long long *>(o);
+            auto pk = [](float a, float b) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32); };
+            st<2>(o8, pk((float)p[0], (float)p[1])); st<2>(o8 + 1, pk((float)p[2], (float)v[0])); st<2>(o8 + 2, pk((float)v[1], (float)v[2]));
+            return;
+        }
         float2 *o2 = reinterpret_cast<float2 *>(o);
         o2[0] = make_float2((float)p[0], (float)p[1]); o2[1] = make_float2((float)p[2], (float)v[0]); o2[2] = make_float2((float)v[1], (float)v[2]);
         return;
@@ -183,6 +217,16 @@ __device__ __forceinline__ f2 pk_sub(f2 a, f2 b)
 }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
+
+// The value of lane - 1 (lane 0: of lane 63): a full-wave rotation by one lane on the vector unit (DPP wave_ror:1), no LDS
+// round trip.  The N = 64 pair loops hand a result to "lane + k" by letting an accumulator TRAVEL: it takes the k = 31
+// result on board first and moves one lane per step, so that what lane i put in at step k has moved k lanes when the loop
+// is through (tools/micro/dpp_rot.hip: 31 hand-overs 0.96 us against 1.42 us through ds_bpermute_b32 at 16 waves per CU).
+#ifndef MRS_DPP_HANDOVER
+#define MRS_DPP_HANDOVER 1
+#endif
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_ror1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); }
 
 // bit-packed adjacency row of agent i from the env's LDS position tile (MRS.calc_A, MRS.py:117-124):
 // float32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it, sqrt(d2) <= R
@@ -328,16 +372,43 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             asm volatile("" : "+v"(thr));
             float rc2 = A.pair_rc2;
             asm volatile("" : "+v"(rc2));
-            uint32_t hm = 0; // neighbours k = 1..31 within quad-quad contact range, bit k; the antipode k = 32 in `ht`
-            bool ht = false;
+            // Quad-quad contact range: the loop only keeps the SMALLEST squared distance this lane has seen (one v_min3_f32
+            // per two pairs; round 2 built a bit per pair, three instructions each, for an event that concerns 0.1-0.3 % of
+            // the envs).  A wave in which some lane's minimum is within range walks its 32 pairs again, below.
+            float dmin = __builtin_huge_valf();
             // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
             // (unless the contact flag wants the distances: the second loop)
             const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
             if (!comm_inf) {
                 // (consuming the handed-over verdicts one pass late, as the downwash loop does with its terms, was measured:
                 // no gain, 26.3 against 26.3 us per step)
+#if MRS_DPP_HANDOVER
+                // k descending: the travelling word hr takes verdict k on board at bit k and moves on one lane (see wave_ror1)
                 auto verdict = [&](int k, float d2) {
-                    hm |= d2 <= rc2 ? (1u << k) : 0u;
+                    const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
+                    lo |= bit;
+                    hr = (k == 31 ? 0u : wave_ror1(hr)) | bit;
+                };
+                {   // k = 31, and k = 32: relative bit 32 is tested by both ends
+                    f2 rx, ry, rz;
+                    tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                    verdict(31, d2.x);
+                    top = d2.y <= thr ? 1u : 0u;
+                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+                }
+#pragma unroll
+                for (int k = 29; k >= 1; k -= 2) { // two neighbours per pass: d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
+                    f2 rx, ry, rz;
+                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                    verdict(k + 1, d2.y);
+                    verdict(k, d2.x);
+                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+                }
+                hr = wave_ror1(hr); // the k = 1 verdict's one step
+#else
+                auto verdict = [&](int k, float d2) {
                     const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
                     lo |= bit;
                     hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
@@ -349,6 +420,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                     const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
                     verdict(k, d2.x);
                     verdict(k + 1, d2.y);
+                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
                 }
                 {   // k = 31, and k = 32: relative bit 32 is tested by both ends
                     f2 rx, ry, rz;
@@ -356,23 +428,33 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                     const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
                     verdict(31, d2.x);
                     top = d2.y <= thr ? 1u : 0u;
-                    ht = d2.y <= rc2;
+                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
                 }
+#endif
             } else if (want_hit) { // no rows wanted (RETURN_A = False) or all ones: the contact range only, nothing to hand over
 #pragma unroll
                 for (int k = 1; k < 33; k += 2) {
                     f2 rx, ry, rz;
                     tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
                     const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    hm |= d2.x <= rc2 ? (1u << k) : 0u;
-                    if (k + 1 < 32) hm |= d2.y <= rc2 ? (2u << k) : 0u; else ht = d2.y <= rc2;
+                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
                 }
             }
             if (want_hit) { // the wave is the env; every unordered pair was tested once (the antipodes by both ends)
-                const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
-                const uint64_t testers = __builtin_amdgcn_ballot_w64(cnt != 0);
+                const uint64_t testers = __builtin_amdgcn_ballot_w64(dmin <= rc2);
                 int flag = 0;
                 if (testers != 0) { // rare (a fraction of a percent of the envs of the benchmark rollout)
+                    // which of its pairs: neighbours k = 1..31 within range at bit k of hm, the antipode k = 32 in ht
+                    // (the same float32 operations as the loop above, hence the same verdicts)
+                    uint32_t hm = 0;
+                    bool ht = false;
+#pragma unroll 1
+                    for (int k = 1; k <= 32; ++k) {
+                        const float rx = f32sub(t[k], mine.x), ry = f32sub(t[128 + k], mine.y), rz = f32sub(t[256 + k], mine.z);
+                        const bool in = f32fma(rz, rz, f32fma(ry, ry, f32mul(rx, rx))) <= rc2;
+                        if (k < 32) hm |= in ? (1u << k) : 0u; else ht = in;
+                    }
+                    const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
                     flag = MRS_PAIR_ROWS; // several pairs: every lane notes its partners (below)
                     const int a = __builtin_ctzll(testers), nb = __builtin_popcountll(testers);
                     if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
@@ -397,7 +479,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             }
             const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
             const uint64_t rel = comm_inf ? ~1ull : (((uint64_t)hi << 32) | lo);
-            if (row) row[0] = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+            if (row && KO_KEEP(2)) st<2>(row, (uint64_t)(lane ? ((rel << lane) | (rel >> (64 - lane))) : rel));
         }
     } else {
         bool hit = false;
@@ -432,6 +514,41 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 {
     const DownwashRegs dr = downwash_regs(dc);
     const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
+#if MRS_DPP_HANDOVER
+    // Magnitudes are summed and the sign is applied once at the end (-(a + b) == (-a) + (-b) bit for bit).  The terms a lane
+    // keeps: float32 partial sums of two per pass, flushed to float64 every four passes.  The terms for the lower quadcopter
+    // of a pair travel to it in `trav` (see wave_ror1), k descending; a lane receives 31 of them as one float32 sum.
+    f2 keep = {0.f, 0.f};
+    float trav = 0.f;
+    double dkeep = 0.;
+    const auto mag2 = [&](f2 d2, f2 rz) { return downwash_mag2_pk(d2, rz, dr); };
+    const auto mine_of = [](float m, float rz, float d2) { return (rz > 0.f && d2 < 100.f) ? m : 0.f; };  // the neighbour is above: this lane's term
+    const auto theirs_of = [](float m, float rz, float d2) { return (rz < 0.f && d2 < 100.f) ? m : 0.f; }; // below: the neighbour's (0 when dz == 0)
+    {   // k = 31, and the antipode k = 32, which both ends evaluate (each keeps its own term)
+        f2 rx, ry, rz;
+        tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+        const f2 m = mag2(d2, rz);
+        keep = f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+        trav = theirs_of(m.x, rz.x, d2.x);
+    }
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const int k = 29 - 2 * j;
+        hook(j);
+        f2 rx, ry, rz;
+        tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+        const f2 m = mag2(d2, rz);
+        trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
+        trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
+        keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+        asm volatile("" : "+v"(keep)); // formed here, not sunk to the end of the loop
+        if ((j & 3) == 3) { dkeep += (double)f32add(keep.x, keep.y); keep = f2{0.f, 0.f}; }
+    }
+    dkeep += (double)f32add(keep.x, keep.y);
+    return -(dkeep + (double)wave_ror1(trav));
+#else
     f2 acc = {0.f, 0.f}; // .x: the terms this lane keeps, .y: the terms handed to it -- one packed add per pair
     float pend = 0.f;
     double dacc = 0.;
@@ -471,6 +588,7 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
         dacc += (double)f32add(acc.x, acc.y);
     }
     return dacc;
+#endif
 }
 
 // Quad-quad contact of lane i with one other agent (oracle/mrs_oracle.c:pair_contact, the same float32 operations): the
@@ -540,6 +658,9 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 #endif
 #ifndef MRS_P_SOLVE
 #define MRS_P_SOLVE 3
+#endif
+#ifndef MRS_REST_SHORTCUT
+#define MRS_REST_SHORTCUT 1 // A/B switch of round 3 (tools/abl_build.sh): 0 sends every grounded body through the sweeps
 #endif
 #ifndef MRS_FUSED_WAVES
 // the fused kernels are held to 128 VGPRs = 4 resident waves per SIMD = all 1024 workgroups of the bench swarm
@@ -754,7 +875,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // Runs FIRST, while only the 13 state words are live: the controller's registers (PID memory,
         // rotation matrices) do not have to survive the 64-iteration loop, which is what keeps the
         // kernel at 4 resident waves per SIMD.
-        if (ACT != MRS_ACT_NONE && !ring) {
+        if (ACT != MRS_ACT_NONE && !ring && KO_KEEP(8)) {
             const float4 *tile_env = lds_tile + el * AN;
             const DownwashConst &dc = A.dc;
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
@@ -827,10 +948,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     s.lvx = g[12 * T]; s.lvy = g[13 * T]; s.lvz = g[14 * T];
                     s.ltx = g[15 * T]; s.lty = g[16 * T]; s.ltz = g[17 * T];
                     ta = vel_control_accel(P, s, o0, act[0], act[1], act[2]);
-                    g[3 * T] = (float)s.dvx; g[4 * T] = (float)s.dvy; g[5 * T] = (float)s.dvz;
-                    g[6 * T] = (float)s.ivx; g[7 * T] = (float)s.ivy; g[8 * T] = (float)s.ivz;
-                    g[12 * T] = s.lvx; g[13 * T] = s.lvy; g[14 * T] = s.lvz;
-                    g[15 * T] = s.ltx; g[16 * T] = s.lty; g[17 * T] = s.ltz;
+                    if (KO_KEEP(4)) {
+                    st<4>(g + 3 * T, (float)s.dvx); st<4>(g + 4 * T, (float)s.dvy); st<4>(g + 5 * T, (float)s.dvz);
+                    st<4>(g + 6 * T, (float)s.ivx); st<4>(g + 7 * T, (float)s.ivy); st<4>(g + 8 * T, (float)s.ivz);
+                    st<4>(g + 12 * T, s.lvx); st<4>(g + 13 * T, s.lvy); st<4>(g + 14 * T, s.lvz);
+                    st<4>(g + 15 * T, s.ltx); st<4>(g + 16 * T, s.lty); st<4>(g + 17 * T, s.ltz);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -857,7 +980,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     if (ACT == MRS_ACT_TARGET_ACCEL) ta = v3((double)act[0], (double)act[1], (double)act[2]);
                     accel_control(P, A.rc, s, ta, R, ob, rpm);
                 }
-                g[9 * T] = (float)s.iox; g[10 * T] = (float)s.ioy; g[11 * T] = (float)s.ioz;
+                if (KO_KEEP(4)) { st<4>(g + 9 * T, (float)s.iox); st<4>(g + 10 * T, (float)s.ioy); st<4>(g + 11 * T, (float)s.ioz); }
             } else if (ACT == MRS_ACT_SET_CONTROL) {
                 set_control(P, act[0], act[1], act[2], act[3], rpm);
             } else {
@@ -991,9 +1114,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     }
     if (doit) {
         TL(3); // forces + velocity integration
+        // near the ground; a body lying flat at rest is finished here, in its own lane (contact_at_rest)
+        const bool grounded = needs_contact(A.P.enable_contact, A.park_z, p[2]) && !(MRS_REST_SHORTCUT && contact_at_rest(A.P, A.rc, p[2], q, v, w));
         if (FUSED) {
-            parked = needs_contact(A.P.enable_contact, A.park_z, p[2]);
-        } else if (needs_contact(A.P.enable_contact, A.park_z, p[2])) {
+            parked = grounded;
+        } else if (grounded) {
             // near the ground: queue the body for k_contact (compacted: the solver's cost scales with the
             // number of grounded bodies, and its registers stay out of this kernel).  Its pre-step pose and
             // unconstrained velocities travel in the slot-indexed planes of contact_state, so k_contact
@@ -1079,15 +1204,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // instead of one burst ahead of it -- was measured: no gain, 27.0 against 27.0 us per step)
         if (doit) {
             integrate_pose(A.P, p, q, v, w);
-            store_state(wb, la, T, p, q, v, w);
+            if (KO_KEEP(1)) store_state(wb, la, T, p, q, v, w);
         }
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         TL(7); // pose + store
-        if (A.b.obs && live && A.n_obs > 0)
+        if (A.b.obs && live && A.n_obs > 0 && KO_KEEP(2))
             write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
-        if (A.do_adj || A.pair_flag != nullptr) {
+        if ((A.do_adj || A.pair_flag != nullptr) && KO_KEEP(16)) {
             // (the env index is formed again from an opaque copy of the thread index: kept live from the top of the kernel
             // it was the one register too many across the contact sweeps)
             int t2 = tid;
@@ -1455,6 +1580,7 @@ struct MrsHandle {
     unsigned step_parity;
     int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
     unsigned long long *pair_rows; // device workspace [T][W]: the candidates per agent (StepArgs.pair_rows)
+    bool big_lds[MRS_ACT_TARGET_ORI + 1]; // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device, per ACTION_TYPE
     float4 *eul_key;    // device workspace, fused step: Euler angles carried from a step's observation slice to the next
     double *eul_ang;    //   step's attitude controller (see MRS_EUL_CARRY): float32 quaternion key [T], float64 angles [3][T]
 };
@@ -1713,12 +1839,20 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
         const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + (size_t)(h->sblock / 64) * sizeof(int);
         if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true>), dim3(g), dim3(128), l, st, B);
         else if (h->sblock == 512) { // 74 KB of LDS per workgroup: above the 64 KB default limit of a launch
-            static bool big_lds = false; // per ACTION_TYPE instantiation; a handle is not thread-safe (include/mrs_hip.h)
-            if (!big_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); big_lds = true; }
+            // The attribute belongs to the (function, device) pair and a process may hold handles on several devices: noted per
+            // handle (a handle is bound to one device and is not thread-safe, include/mrs_hip.h) and per ACTION_TYPE instantiation.
+            if (!h->big_lds[ACT]) {
+                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                if (ea != hipSuccess) return ea;
+                h->big_lds[ACT] = true;
+            }
             hipLaunchKernelGGL((k_step<ACT, 512, true>), dim3(g), dim3(512), l, st, B);
         } else if (h->sblock == 1024) {
-            static bool big_lds = false;
-            if (!big_lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); big_lds = true; }
+            if (!h->big_lds[ACT]) {
+                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                if (ea != hipSuccess) return ea;
+                h->big_lds[ACT] = true;
+            }
             hipLaunchKernelGGL((k_step<ACT, 1024, true>), dim3(g), dim3(1024), l, st, B);
         }
         else hipLaunchKernelGGL((k_step<ACT, 64, true>), dim3(g), dim3(64), l, st, B);
@@ -1766,6 +1900,9 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
     if (rc) return rc;
     A.actions = actions;
+#if MRS_KO == -1
+    { const char *ko = getenv("MRS_KO"); A.ko = ko ? atoi(ko) : 0; }
+#endif
     // alternating counters: this step's k_step adds to ws[parity] (read by this step's k_contact) and
     // zeroes ws[parity^1] for the next step -- stream order makes that safe without a memset node
     if (h->ws) {

@@ -37,18 +37,38 @@ def init_from_env(backend=None):
 
 
 class ObsAllGather:
-    """all-gather of (E_local, N, D) slices into (world*E_local, N, D), overlapped with compute."""
+    """all-gather of the ranks' (E_local, N, D) slices into (sum of E_local, N, D) in rank order, overlapped with compute.
+    The shards may differ in size (E not divisible by the world size)."""
 
     def __init__(self, e_local, n_agents, d, device, group=None, buffers=2):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
-        self.out = [torch.empty(self.world * e_local, n_agents, d, dtype=torch.float32, device=self.device)
-                    for _ in range(buffers)]
-        self.k = 0
         self.cuda = self.device.type == "cuda"
+        self.e_local = int(e_local)
+        # shard sizes of every rank (shard_range hands the remainder of E % world to the low ranks): exchanged once here
+        if self.world > 1:
+            mine = torch.tensor([self.e_local], dtype=torch.int64, device=self.device)
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(every, mine, group=group)
+            self.sizes = [int(t.item()) for t in every]
+        else:
+            self.sizes = [self.e_local]
+        self.offsets = [sum(self.sizes[:r]) for r in range(self.world)]
+        self.e_max = max(self.sizes)
+        self.uneven = min(self.sizes) != self.e_max
+        self.out = [torch.empty(sum(self.sizes), n_agents, d, dtype=torch.float32, device=self.device) for _ in range(buffers)]
+        # unequal shards: the collective needs equal contributions, so every rank sends e_max envs (its slice, zero-padded)
+        # and the valid parts are compacted into `out` behind the collective, on the same side stream
+        self.stage = [torch.zeros(self.e_max, n_agents, d, dtype=torch.float32, device=self.device) for _ in range(buffers)] if self.uneven else None
+        self.padded = [torch.empty(self.world * self.e_max, n_agents, d, dtype=torch.float32, device=self.device) for _ in range(buffers)] if self.uneven else None
+        self.k = 0
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.done = [None] * buffers
+
+    def _compact(self, k):
+        for r in range(self.world):
+            self.out[k][self.offsets[r]:self.offsets[r] + self.sizes[r]].copy_(self.padded[k][r * self.e_max:r * self.e_max + self.sizes[r]])
 
     def gather(self, newest):
         """Start gathering `newest` (contiguous (E_local,N,D)); returns the output buffer, complete after wait().
@@ -70,14 +90,24 @@ class ObsAllGather:
             cur = torch.cuda.current_stream(self.device)
             if self.done[k] is not None:
                 cur.wait_event(self.done[k])                             # back-pressure: gather t - buffers has landed
+            src = newest
+            if self.uneven:
+                self.stage[k][:self.e_local].copy_(newest)               # on the caller's stream, behind the step kernel
+                src = self.stage[k]
             ready = torch.cuda.Event()
             ready.record(cur)                                            # the step kernel that wrote `newest`
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                dist.all_gather_into_tensor(out, newest, group=self.group)
+                dist.all_gather_into_tensor(self.padded[k] if self.uneven else out, src, group=self.group)
+                if self.uneven:
+                    self._compact(k)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             self.done[k] = ev
+        elif self.uneven:
+            self.stage[k][:self.e_local].copy_(newest)
+            dist.all_gather(list(self.padded[k].chunk(self.world, dim=0)), self.stage[k], group=self.group)
+            self._compact(k)
         else:
             parts = list(out.chunk(self.world, dim=0))
             dist.all_gather(parts, newest.contiguous(), group=self.group)
@@ -95,6 +125,13 @@ def gather_global_state(local, group=None):
     """Concatenate per-rank (E_local, ...) tensors in rank order (tests: 1-GPU vs sharded bitwise equality)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
-    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return torch.cat(parts, 0)
+    world = dist.get_world_size(group)
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    sizes = [int(t.item()) for t in every]
+    pad = torch.zeros((max(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)   # shards may differ by one env
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)

@@ -534,10 +534,23 @@ static void matTvec(const double R[9], const double v[3], double o[3])
  * cap of the collision cylinder faces the ground,
  * Bullet-style velocity-level rhs (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint),
  * sequential impulses with a friction pyramid along world x/y. */
+/* Diagnostic tap (tools/contact_lab.py, single-threaded runs only): the inputs of every contact problem, 16 doubles each
+ * (z, R[9], v[3], w[3]), for offline experiments with the solver. */
+static double *g_cdump = 0;
+static long g_cdump_cap = 0, g_cdump_n = 0;
+void orc_contact_dump(double *buf, long cap) { g_cdump = buf; g_cdump_cap = cap; g_cdump_n = 0; }
+long orc_contact_dump_count(void) { return g_cdump_n; }
+
 static void contact_solve(const OrcParams *p, const double pos[3], const double R[9], double v[3], double w[3])
 {
     const double bound = sqrt(p->coll_radius * p->coll_radius + p->coll_half_len * p->coll_half_len);
     if (pos[2] - bound - p->contact_threshold > p->ground_z) return;
+    if (g_cdump && g_cdump_n < g_cdump_cap) {
+        double *d = g_cdump + 16 * g_cdump_n++;
+        d[0] = pos[2];
+        for (int k = 0; k < 9; ++k) d[1 + k] = R[k];
+        for (int k = 0; k < 3; ++k) { d[10 + k] = v[k]; d[13 + k] = w[k]; }
+    }
     const double c = p->coll_radius * 0.70710678118654752440;
     double r[8][3], dist[8], lam_n[8], lam_t[8][2], kn[8], kt[8][2], rhs[8];
     int active[8], nact = 0;

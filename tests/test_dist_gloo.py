@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 from util_scenarios import ActionStream, grid_spawn
 
-E_TOTAL, N, STEPS, ATYPE = 6, 12, 25, "set_target_vel"
+E_TOTAL, N, STEPS, ATYPE = 7, 12, 25, "set_target_vel"   # 7 envs over 2 ranks: shards of 4 and 3 (unequal on purpose)
 
 
 def _free_port():

@@ -38,6 +38,8 @@ t = 0
 for _ in range(ROLLIN):
     sh.step_ptr(table[t // 50], at, obs.data_ptr(), adj.data_ptr(), 5.0); t += 1
 torch.cuda.synchronize()
+if os.environ.get("KO"):            # a -DMRS_KO=-1 build: parts of the step switched off for the timed steps only (tools/abl_run.sh "name:KO=3")
+    os.environ["MRS_KO"] = os.environ["KO"]
 res = []
 for r in range(REPS):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
