@@ -634,24 +634,42 @@ struct F3 {
 typedef float F2 __attribute__((ext_vector_type(2)));
 // Returns the velocity CHANGES (dv, dw) in float32; the caller adds them to the float64 state (the fused kernel re-reads
 // that from its LDS stash afterwards, so no float64 velocity stays live across the sweeps).
-MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const M3 &R, const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out,
+MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const double q[4], const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out,
                                float *diag = nullptr)
 {
+    // Every product-sum below is written out with explicit fused multiply-adds under "contract(off)": the function is inlined
+    // into several kernels (one-launch step, k_contact) and must round the same way in all of them.
+#pragma clang fp contract(off)
     dv_out = F3{0.f, 0.f, 0.f}; dw_out = F3{0.f, 0.f, 0.f};
-    const double c = P.coll_radius * 0.70710678118654752440, hl = P.coll_half_len;
+    // Everything from here on is float32, the geometry included (round 3; round 2 formed the rotation matrix, the rim points'
+    // heights, the gaps and the right-hand sides in float64: ~150 float64 instructions and conversions at the head of the
+    // workgroup's one serial chain).  What float32 costs: the levers (|r| <= 0.061 m) carry the quaternion's rounding, < 1e-8 m;
+    // the gap is the float32 of (pz - ground_z), rounded once from the float64 difference, plus the lever's z, < 2e-9 m off;
+    // times 1 / dt that is < 2e-7 m/s on a right-hand side -- three orders inside the stated 1e-4 per step.
+    const float c = (float)(P.coll_radius * 0.70710678118654752440), hl = (float)P.coll_half_len;
     const float i0 = (float)K.inv_i0, i1 = (float)K.inv_i1, i2 = (float)K.inv_i2;
     const float im = (float)K.inv_mass;
-    const float r00 = (float)R.m00, r01 = (float)R.m01, r02 = (float)R.m02, r10 = (float)R.m10, r11 = (float)R.m11,
-                r12 = (float)R.m12, r20 = (float)R.m20, r21 = (float)R.m21, r22 = (float)R.m22;
-    const float Ixx = r00 * r00 * i0 + r01 * r01 * i1 + r02 * r02 * i2, Ixy = r00 * r10 * i0 + r01 * r11 * i1 + r02 * r12 * i2,
-                Ixz = r00 * r20 * i0 + r01 * r21 * i1 + r02 * r22 * i2, Iyy = r10 * r10 * i0 + r11 * r11 * i1 + r12 * r12 * i2,
-                Iyz = r10 * r20 * i0 + r11 * r21 * i1 + r12 * r22 * i2, Izz = r20 * r20 * i0 + r21 * r21 * i1 + r22 * r22 * i2;
-    const double cxz = c * R.m20, cyz = c * R.m21; // z of the rim points in float64 (gap cancellation)
-    // only the rim of the cap facing the ground carries contacts (oracle: lower_cap): fold its sign into cz
-    const double sgn = (R.m22 >= 0) ? -1.0 : 1.0;
-    const double czz = sgn * (hl * R.m22);
-    const F3 cx = {(float)(c * R.m00), (float)(c * R.m10), (float)cxz}, cy = {(float)(c * R.m01), (float)(c * R.m11), (float)cyz},
-             cz = {(float)(sgn * hl * R.m02), (float)(sgn * hl * R.m12), (float)czz};
+    const auto fm = [](float a, float b, float c) { return __builtin_fmaf(a, b, c); };
+    // btMatrix3x3::setRotation of the float32 quaternion, s = 2 / |q|^2
+    const float qx = (float)q[0], qy = (float)q[1], qz = (float)q[2], qw = (float)q[3];
+    const float s2 = 2.0f * __builtin_amdgcn_rcpf(fm(qx, qx, fm(qy, qy, fm(qz, qz, qw * qw))));
+    const float xs = qx * s2, ys = qy * s2, zs = qz * s2;
+    const float r00 = 1.0f - fm(qy, ys, qz * zs), r01 = fm(qx, ys, -(qw * zs)), r02 = fm(qx, zs, qw * ys);
+    const float r10 = fm(qx, ys, qw * zs), r11 = 1.0f - fm(qx, xs, qz * zs), r12 = fm(qy, zs, -(qw * xs));
+    const float r20 = fm(qx, zs, -(qw * ys)), r21 = fm(qy, zs, qw * xs), r22 = 1.0f - fm(qx, xs, qy * ys);
+    // world inverse inertia R diag(i0, i1, i2) R^T
+    const float a00 = r00 * i0, a01 = r01 * i1, a02 = r02 * i2, a10 = r10 * i0, a11 = r11 * i1, a12 = r12 * i2;
+    const float Ixx = fm(a00, r00, fm(a01, r01, a02 * r02)), Ixy = fm(a00, r10, fm(a01, r11, a02 * r12)), Ixz = fm(a00, r20, fm(a01, r21, a02 * r22));
+    const float Iyy = fm(a10, r10, fm(a11, r11, a12 * r12)), Iyz = fm(a10, r20, fm(a11, r21, a12 * r22));
+    const float Izz = fm(r20 * i0, r20, fm(r21 * i1, r21, (r22 * i2) * r22));
+    // only the rim of the cap facing the ground carries contacts (oracle: lower_cap): fold its sign into the cap's offset
+    const float shl = (r22 >= 0.f) ? -hl : hl;
+    const F3 cz = {shl * r02, shl * r12, shl * r22};
+    // the four rim points (+-c, +-c) in the cap's plane: centre offset +- (cx + cy) and +- (cx - cy)
+    const F3 ca = {c * (r00 + r01), c * (r10 + r11), c * (r20 + r21)}, cb = {c * (r00 - r01), c * (r10 - r11), c * (r20 - r21)};
+    const float d0 = (float)(pz - P.ground_z);
+    const float thr = (float)P.contact_threshold, rdt = (float)K.inv_dt, erdt = (float)(P.erp * K.inv_dt);
+    const float v0z = (float)v.z;
     bool any = false;
     float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
     // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows.
@@ -661,42 +679,43 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     F3 r[4];
     F2 anxy[4], axxy[4], ayxy[4]; // x, y of the angular responses as pairs: dw.xy += a.xy * dl is one packed fma
     float anz[4], axz[4], ayz[4];
-    const double rdt = K.inv_dt;
+    const float w0x = (float)w.x, w0y = (float)w.y, w0z = (float)w.z;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ln[k] = lx[k] = ly[k] = 0.f;
-        const double rzd = ((k & 1) ? -cxz : cxz) + ((k & 2) ? -cyz : cyz) + czz;
-        const double dist = pz + rzd - P.ground_z;
-        const bool act = dist <= P.contact_threshold;
-        any |= act;
-        const float rx = ((k & 1) ? -cx.x : cx.x) + ((k & 2) ? -cy.x : cy.x) + cz.x;
-        const float ry = ((k & 1) ? -cx.y : cx.y) + ((k & 2) ? -cy.y : cy.y) + cz.y;
-        const float rz = (float)rzd; // lever z rounded once from float64 (as the oracle's gap)
+        // k & 1: -cx, k & 2: -cy  =>  k = 0: +ca, 1: -cb, 2: +cb, 3: -ca
+        const F3 &o = (k == 0 || k == 3) ? ca : cb;
+        const bool plus = (k == 0 || k == 2);
+        const float rx = plus ? cz.x + o.x : cz.x - o.x, ry = plus ? cz.y + o.y : cz.y - o.y, rz = plus ? cz.z + o.z : cz.z - o.z;
         r[k] = F3{rx, ry, rz};
+        const float dist = d0 + rz;
+        const bool act = dist <= thr;
+        any |= act;
         // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
-        const F3 an = {Ixx * ry - Ixy * rx, Ixy * ry - Iyy * rx, Ixz * ry - Iyz * rx};
-        const F3 ax = {Ixy * rz - Ixz * ry, Iyy * rz - Iyz * ry, Iyz * rz - Izz * ry};
-        const F3 ay = {-Ixx * rz + Ixz * rx, -Ixy * rz + Iyz * rx, -Ixz * rz + Izz * rx};
+        const F3 an = {fm(Ixx, ry, -(Ixy * rx)), fm(Ixy, ry, -(Iyy * rx)), fm(Ixz, ry, -(Iyz * rx))};
+        const F3 ax = {fm(Ixy, rz, -(Ixz * ry)), fm(Iyy, rz, -(Iyz * ry)), fm(Iyz, rz, -(Izz * ry))};
+        const F3 ay = {fm(Ixz, rx, -(Ixx * rz)), fm(Iyz, rx, -(Ixy * rz)), fm(Izz, rx, -(Ixz * rz))};
         anxy[k] = F2{an.x, an.y}; anz[k] = an.z; axxy[k] = F2{ax.x, ax.y}; axz[k] = ax.z; ayxy[k] = F2{ay.x, ay.y}; ayz[k] = ay.z;
         // effective masses 1 / (1/m + (r x d) . Iw (r x d))
-        const float kn = __builtin_amdgcn_rcpf(im + (ry * an.x - rx * an.y));
-        const float kx = __builtin_amdgcn_rcpf(im + (rz * ax.y - ry * ax.z));
-        const float ky = __builtin_amdgcn_rcpf(im + (rx * ay.z - rz * ay.x));
+        const float kn = __builtin_amdgcn_rcpf(fm(ry, an.x, fm(-rx, an.y, im)));
+        const float kx = __builtin_amdgcn_rcpf(fm(rz, ax.y, fm(-ry, ax.z, im)));
+        const float ky = __builtin_amdgcn_rcpf(fm(rx, ay.z, fm(-rz, ay.x, im)));
         Kn[k] = act ? kn : 0.f; Kx[k] = act ? kx : 0.f; Ky[k] = act ? ky : 0.f;
-        const double vrel0 = v.z + (w.x * (double)ry - w.y * (double)rx);
+        const float vrel0 = fm(w0x, ry, fm(-w0y, rx, v0z));
         // Bullet-style rhs: open gap -> let the point close it this step; penetration -> erp push-out
-        rhs[k] = (float)(-vrel0 - dist * (dist > 0 ? rdt : P.erp * rdt));
+        rhs[k] = fm(-dist, dist > 0.f ? rdt : erdt, -vrel0);
+        __builtin_amdgcn_sched_barrier(0); // one point after the other: interleaved, the four points' temporaries cost three spilled registers
     }
     if (!any) return;
-    const float v0x = (float)v.x, v0y = (float)v.y, w0x = (float)w.x, w0y = (float)w.y, w0z = (float)w.z;
+    const float v0x = (float)v.x, v0y = (float)v.y;
     const float mu = (float)P.friction;
     // tangential point velocities of the pre-solve state, per point: the friction rows then need only the CHANGES
     // dv, dw (3 fused operations per row instead of re-forming v0 + dv, w0 + dw every time)
     float c0x[4], c0y[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        c0x[k] = v0x + (w0y * r[k].z - w0z * r[k].y);
-        c0y[k] = v0y + (w0z * r[k].x - w0x * r[k].z);
+        c0x[k] = fm(w0y, r[k].z, fm(-w0z, r[k].y, v0x));
+        c0y[k] = fm(w0z, r[k].x, fm(-w0x, r[k].z, v0y));
     }
     float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwz = 0.f;
     F2 dwxy = {0.f, 0.f};
@@ -708,7 +727,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
         float nact = 0.f, rsum = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const bool a = Kn[k] != 0.f; nact += a ? 1.f : 0.f; rsum += a ? rhs[k] : 0.f; }
-        const float l0 = nact > 0.f ? fmaxf(rsum, 0.f) / (nact * nact * im) : 0.f; // m * mean(rhs) / n
+        const float l0 = nact > 0.f ? fmaxf(rsum, 0.f) * __builtin_amdgcn_rcpf(nact * nact * im) : 0.f; // m * mean(rhs) / n
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float l = Kn[k] != 0.f ? l0 : 0.f;
@@ -789,15 +808,22 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 // A body LYING FLAT AT REST on the ground (nine out of ten grounded bodies of a rollout: crashed quadcopters whose rotor
 // torques cancel) is the one case in which the sweeps of contact_solve_f32 have nothing to do: all four rim points are
 // active with the same gap and the same closing velocity, the equal-share start IS the solution (every point carries a
-// quarter of the impulse that stops the body, dv_z = max(rhs, 0)), the normal rows find rhs - dv_n = 0 and the friction
-// rows a tangential velocity of 0.  Evaluated here in the body's own lane: such a body is never listed for the solve.
-// "At rest": |R20|, |R21|, |w|, |v_xy| < 1e-9 and the common gap not within 1e-9 of the contact threshold -- the rim points'
-// gaps then differ by < 1.2e-10 m and their closing velocities by < 1.2e-10 m/s from the values used here, i.e. the result
-// is within ~3e-8 m/s of what the sweeps return (oracle/mrs_oracle.c:contact_solve has no such shortcut; the parity tests
-// compare the two).  Returns true when the body is dealt with (v updated, or no point within the threshold).
-MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, const double q[4], double v[3], const double w[3])
+// quarter of the impulse that stops the body, dv_z = max(rhs, 0)), and the friction rows hold the four points where they
+// are: v_xy = 0, w = 0.  Evaluated here in the body's own lane: such a body is never listed for the solve.
+// "At rest": |R20|, |R21|, |w|, |v_xy| < MRS_REST_EPS = 1e-6 -- the float32 sweeps leave residuals of 1e-8 ... 1e-7 on a body they
+// have just put down, so a tighter bound is never met on the GPU (measured: with 1e-9 no body ever took this path) -- and
+// the common gap not within that margin of the contact threshold.  Against the sweeps' own result: the rim points' gaps
+// differ by < 1.2e-7 m, i.e. their right-hand sides by < 1.2e-5 m/s, and the velocities set to zero here are ones the
+// sweeps would have brought to within 1e-7 of zero; 1e-5 m/s per step is inside the stated 1e-4 (oracle/mrs_oracle.c:
+// contact_solve has no such shortcut; the parity tests compare the two through touchdown and rest).
+// A body that is being lifted (rhs <= 0: no normal impulse, hence no friction) keeps its velocities.
+// Returns true when the body is dealt with (v, w updated, or no point within the threshold).
+#ifndef MRS_REST_EPS
+#define MRS_REST_EPS 1e-6
+#endif
+MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, const double q[4], double v[3], double w[3])
 {
-    const double eps = 1e-9;
+    const double eps = MRS_REST_EPS;
     // third row of btMatrix3x3::setRotation for a unit quaternion (|q|^2 - 1 ~ 1e-16 after every step's normalisation; a
     // caller's own non-unit quaternion fails the tests below or changes the bound by its relative error)
     const double r20 = 2.0 * (q[0] * q[2] - q[3] * q[1]), r21 = 2.0 * (q[1] * q[2] + q[3] * q[0]);
@@ -807,16 +833,22 @@ MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, con
     if (!(big < eps) || !(fabs(dist - P.contact_threshold) > eps)) return false;
     if (dist > P.contact_threshold) return true; // flat and clear of the ground: no point within the threshold
     const double rhs = -v[2] - dist * (dist > 0 ? K.inv_dt : P.erp * K.inv_dt);
-    v[2] += fmax(rhs, 0.0);
+    if (rhs > 0.0) {
+        // sticking needs friction impulses of m |v_xy| and ~I |w| / r (< 1e-3 of that): inside the pyramid mu * (m rhs / 4) per
+        // point with room to spare, or the sweeps decide
+        if (!(P.friction * rhs > 8.0 * eps)) return false;
+        v[2] += rhs;
+        v[0] = v[1] = 0.0;
+        w[0] = w[1] = w[2] = 0.0;
+    }
     return true;
 }
 
 MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
 {
-    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
     V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
     F3 dv, dw;
-    contact_solve_f32(P, K, p[2], R, vv, ww, dv, dw);
+    contact_solve_f32(P, K, p[2], q, vv, ww, dv, dw);
     v[0] += (double)dv.x; v[1] += (double)dv.y; v[2] += (double)dv.z;
     w[0] += (double)dw.x; w[1] += (double)dw.y; w[2] += (double)dw.z;
 }
@@ -825,8 +857,7 @@ MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3
 MRS_DEV void contact_stage_delta(const MrsParams &P, const Recips &K, double pz, const double q[4], const double v[3], const double w[3],
                                  F3 &dv, F3 &dw, float *diag = nullptr)
 {
-    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
-    contact_solve_f32(P, K, pz, R, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, diag);
+    contact_solve_f32(P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, diag);
 }
 
 MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[3], const double w[3]);
@@ -843,7 +874,9 @@ MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[
     //   sin(h) / fAngle = (dt/2) sinc(h) = (dt/2) S(x),  cos(h) = C(x),  and the angular-motion threshold is x <= (pi/8)^2
     // (at the threshold both forms agree, so clamping x reproduces that branch; Bullet's small-angle Taylor branch is
     // the first two terms of S, its remainder < 1e-25).  S, C: Taylor to x^7 / x^8, remainder < 1e-17 on x <= (pi/8)^2.
-    p[0] += dt * v[0]; p[1] += dt * v[1]; p[2] += dt * v[2];
+    // (written as the fused multiply-add it is: the one-launch step forms the same expression ahead of time for its
+    // adjacency pass and the two must agree to the bit)
+    p[0] = __builtin_fma(dt, v[0], p[0]); p[1] = __builtin_fma(dt, v[1], p[1]); p[2] = __builtin_fma(dt, v[2], p[2]);
     const double x = fmin(0.25 * (dt * dt) * (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 0.15421256876702122);
     double S = fma_c(x, 1.0 / 1307674368000.0, -1.0 / 6227020800.0);
     S = fma_c(S, x, 1.0 / 39916800.0);

@@ -222,9 +222,6 @@ __device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
 // round trip.  The N = 64 pair loops hand a result to "lane + k" by letting an accumulator TRAVEL: it takes the k = 31
 // result on board first and moves one lane per step, so that what lane i put in at step k has moved k lanes when the loop
 // is through (tools/micro/dpp_rot.hip: 31 hand-overs 0.96 us against 1.42 us through ds_bpermute_b32 at 16 waves per CU).
-#ifndef MRS_DPP_HANDOVER
-#define MRS_DPP_HANDOVER 1
-#endif
 __device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xf, 0xf, false); }
 __device__ __forceinline__ float wave_ror1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); }
 
@@ -330,6 +327,114 @@ __device__ __forceinline__ void tile64_rel2(const float *t, int k, f2 mx, f2 my,
 // at every pair of the env.
 #define MRS_PAIR_ROWS 2
 
+// ---- N = 64: an env is one wave.  The relation is symmetric with bit-identical arithmetic in both directions
+// ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k), k = 1..31, notes it at RELATIVE bit k
+// and hands the verdict to lane i+k, where it is relative bit 64-k; k = 32 is tested by both ends.  The hand-over is a
+// travelling word (wave_ror1), k descending; one 64-bit rotate by the lane index at the end turns relative into
+// absolute columns.  t = the env's tile + lane (tile64_write), (mex, mey, mez) = this lane's own float32 position.
+//   rows = false: COMM_RANGE = inf (MRS.py:118-119: ones - eye whatever the positions are) or no rows wanted
+//   want_hit: also the smallest squared distance this lane has seen (quad-quad contact range: one v_min3_f32 per two pairs;
+//   round 2 built a bit per pair, three instructions each, for an event that concerns 0.1-0.3 % of the envs)
+// (Round 2 experiment, removed: evaluating the NEXT step's downwash in this loop and carrying the force to the next launch:
+// +1.2 us per step, the work moves from the start of the kernel, where issue slots are idle, to its end, where none are.)
+__device__ __forceinline__ void adj64_pass(const float *t, float mex, float mey, float mez, float thr_s, bool rows, bool want_hit, int lane,
+                                           uint64_t &row, float &dmin)
+{
+    // own verdicts at bit k of `lo`; the verdicts from below collect in `hr` at bit k too and are mirrored into place
+    // (relative bit 64-k) by one v_bfrev at the end: one select and two ORs per pair, no per-pair shifts
+    uint32_t lo = 0, hr = 0, top = 0;
+    // The range threshold lives in a VECTOR register for the loop (comm_range = inf arrives as thr = +inf from the host).
+    // As a kernel argument it is re-read from the argument segment inside every pair once scalar registers are short --
+    // s_load + s_waitcnt lgkmcnt(0), which also drains the pair's LDS read: the loop then runs one pair per memory round trip.
+    float thr = thr_s;
+    asm volatile("" : "+v"(thr));
+    dmin = __builtin_huge_valf();
+    const f2 mx = splat(mex), my = splat(mey), mz = splat(mez);
+    if (rows) {
+        auto verdict = [&](int k, float d2) {
+            const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
+            lo |= bit;
+            hr = (k == 31 ? 0u : wave_ror1(hr)) | bit;
+        };
+        {   // k = 31, and k = 32: relative bit 32 is tested by both ends
+            f2 rx, ry, rz;
+            tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+            const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+            verdict(31, d2.x);
+            top = d2.y <= thr ? 1u : 0u;
+            dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+        }
+#pragma unroll
+        for (int k = 29; k >= 1; k -= 2) { // two neighbours per pass: d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
+            f2 rx, ry, rz;
+            tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+            const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+            verdict(k + 1, d2.y);
+            verdict(k, d2.x);
+            dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+        }
+        hr = wave_ror1(hr); // the k = 1 verdict's one step
+    } else if (want_hit) { // the contact range only, nothing to hand over
+#pragma unroll
+        for (int k = 1; k < 33; k += 2) {
+            f2 rx, ry, rz;
+            tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+            const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+            dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+        }
+    }
+    const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
+    const uint64_t rel = rows ? (((uint64_t)hi << 32) | lo) : ~1ull;
+    row = lane ? ((rel << lane) | (rel >> (64 - lane))) : rel;
+}
+
+// StepArgs.pair_flag[e] / pair_rows of an N = 64 env whose tile (t = tile + lane) holds the positions the NEXT step starts
+// from.  near = this lane may have a pair within contact range (exactly so, or conservatively: a wave in which no lane says
+// so has none, a wave in which one does walks its 32 pairs per lane again -- rare, a fraction of a percent of the envs).
+__device__ __forceinline__ void adj64_flag(const StepArgs &A, const float *t, float mex, float mey, float mez, int lane, int e, bool near)
+{
+    float rc2 = A.pair_rc2;
+    asm volatile("" : "+v"(rc2));
+    int flag = 0;
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+        // which of its pairs: neighbours k = 1..31 within range at bit k of hm, the antipode k = 32 in ht
+        // (the same float32 operations as the pass, hence the same distances)
+        uint32_t hm = 0;
+        bool ht = false;
+#pragma unroll 1
+        for (int k = 1; k <= 32; ++k) {
+            const float rx = f32sub(t[k], mex), ry = f32sub(t[128 + k], mey), rz = f32sub(t[256 + k], mez);
+            const bool in = f32fma(rz, rz, f32fma(ry, ry, f32mul(rx, rx))) <= rc2;
+            if (k < 32) hm |= in ? (1u << k) : 0u; else ht = in;
+        }
+        const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
+        const uint64_t testers = __builtin_amdgcn_ballot_w64(cnt != 0);
+        if (testers != 0) {
+            flag = MRS_PAIR_ROWS; // several pairs: every lane notes its partners (below)
+            const int a = __builtin_ctzll(testers), nb = __builtin_popcountll(testers);
+            if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
+                const uint32_t hma = (uint32_t)__builtin_amdgcn_readlane((int)hm, a);
+                if (nb == 1 && hma != 0) {
+                    flag = MRS_PAIR_SINGLE | a | (((a + __builtin_ctz(hma)) & 63) << 8);
+                } else if (nb == 2 && a < 32 && __builtin_amdgcn_ballot_w64(ht && hm == 0) == testers && (testers >> (a + 32)) == 1ull) {
+                    flag = MRS_PAIR_SINGLE | a | ((a + 32) << 8);
+                }
+            }
+            if (flag == MRS_PAIR_ROWS) {
+                // the partners of a lane: the ones it tested itself (hm, relative bit k) and the ones that tested it
+                // (handed to lane + k, mirrored into relative bit 64-k), rotated into absolute columns
+                uint32_t hrh = 0;
+                const int lane4 = lane << 2;
+#pragma unroll
+                for (int k = 1; k < 32; ++k) hrh |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)(hm & (1u << k)));
+                const uint64_t hrel = ((uint64_t)((__builtin_bitreverse32(hrh) << 1) | (ht ? 1u : 0u)) << 32) | hm;
+                A.pair_rows[(size_t)e * 64 + lane] = lane ? ((hrel << lane) | (hrel >> (64 - lane))) : hrel;
+            }
+        }
+    }
+    if (lane == 0) A.pair_flag[e] = flag;
+}
+
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 // Also (A.pair_flag): notes per env whether any pair of it is within quad-quad contact range of these positions -- the
@@ -347,139 +452,14 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
     else { gx[tid] = mine.x; gx[BLOCK + tid] = mine.y; gx[2 * BLOCK + tid] = mine.z; }
     if (n64) wave_lds_sync(); else __syncthreads();
     if (n64) {
-        // N = 64: one wave per env and the relation is symmetric with bit-identical arithmetic in both
-        // directions ((-dx)^2 == dx^2), so each unordered pair is tested once: lane i tests (i, i+k),
-        // k = 1..31, notes it at RELATIVE bit k and passes the verdict to lane i+k (ds_bpermute), where
-        // it is relative bit 64-k; k = 32 is tested by both ends.  One 64-bit rotate by the lane index at
-        // the end turns relative into absolute columns.
-        // (Round 2 experiment, removed: evaluating the NEXT step's downwash in this loop -- it shares the neighbour
-        // read and the differences -- and carrying the force to the next launch.  31.6 against 30.3 us per step, and
-        // 28.8 against 27.6 after the other changes of the round: the work moves from the start of the kernel, where
-        // issue slots are idle while the state loads are in flight, to its end, where none are.)
         if (live) {
             const int lane = tid & 63;
             const float *t = tile64(lds_tile, el) + lane;
-            const int lane4 = lane << 2;
-            // own verdicts at bit k of `lo`; the SAME word travels to lane i+k, whose verdicts from below
-            // collect in `hr` at bit k too and are mirrored into place (relative bit 64-k) by one v_bfrev at
-            // the end: one select and two ORs per pair, no per-pair shifts
-            uint32_t lo = 0, hr = 0, top = 0;
-            // The range threshold lives in a VECTOR register for the loop (comm_range = inf arrives as thr = +inf from
-            // the host).  As a kernel argument it is re-read from the argument segment inside every pair once scalar
-            // registers are short -- s_load + s_waitcnt lgkmcnt(0), which also drains the pair's LDS read and every
-            // cross-lane transfer in flight: the loop then runs one pair per memory round trip.
-            float thr = thr_s;
-            asm volatile("" : "+v"(thr));
-            float rc2 = A.pair_rc2;
-            asm volatile("" : "+v"(rc2));
-            // Quad-quad contact range: the loop only keeps the SMALLEST squared distance this lane has seen (one v_min3_f32
-            // per two pairs; round 2 built a bit per pair, three instructions each, for an event that concerns 0.1-0.3 % of
-            // the envs).  A wave in which some lane's minimum is within range walks its 32 pairs again, below.
-            float dmin = __builtin_huge_valf();
-            // COMM_RANGE = inf (MRS.py:118-119): ones - eye whatever the positions are -- no pair needs looking at
-            // (unless the contact flag wants the distances: the second loop)
-            const f2 mx = splat(mine.x), my = splat(mine.y), mz = splat(mine.z);
-            if (!comm_inf) {
-                // (consuming the handed-over verdicts one pass late, as the downwash loop does with its terms, was measured:
-                // no gain, 26.3 against 26.3 us per step)
-#if MRS_DPP_HANDOVER
-                // k descending: the travelling word hr takes verdict k on board at bit k and moves on one lane (see wave_ror1)
-                auto verdict = [&](int k, float d2) {
-                    const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
-                    lo |= bit;
-                    hr = (k == 31 ? 0u : wave_ror1(hr)) | bit;
-                };
-                {   // k = 31, and k = 32: relative bit 32 is tested by both ends
-                    f2 rx, ry, rz;
-                    tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
-                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    verdict(31, d2.x);
-                    top = d2.y <= thr ? 1u : 0u;
-                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
-                }
-#pragma unroll
-                for (int k = 29; k >= 1; k -= 2) { // two neighbours per pass: d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
-                    f2 rx, ry, rz;
-                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
-                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    verdict(k + 1, d2.y);
-                    verdict(k, d2.x);
-                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
-                }
-                hr = wave_ror1(hr); // the k = 1 verdict's one step
-#else
-                auto verdict = [&](int k, float d2) {
-                    const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
-                    lo |= bit;
-                    hr |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)bit);
-                };
-#pragma unroll
-                for (int k = 1; k < 31; k += 2) { // two neighbours per pass: d2 = fma(dz,dz,fma(dy,dy,dx*dx)) as torch's norm kernel evaluates it
-                    f2 rx, ry, rz;
-                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
-                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    verdict(k, d2.x);
-                    verdict(k + 1, d2.y);
-                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
-                }
-                {   // k = 31, and k = 32: relative bit 32 is tested by both ends
-                    f2 rx, ry, rz;
-                    tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
-                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    verdict(31, d2.x);
-                    top = d2.y <= thr ? 1u : 0u;
-                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
-                }
-#endif
-            } else if (want_hit) { // no rows wanted (RETURN_A = False) or all ones: the contact range only, nothing to hand over
-#pragma unroll
-                for (int k = 1; k < 33; k += 2) {
-                    f2 rx, ry, rz;
-                    tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
-                    const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
-                    dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
-                }
-            }
-            if (want_hit) { // the wave is the env; every unordered pair was tested once (the antipodes by both ends)
-                const uint64_t testers = __builtin_amdgcn_ballot_w64(dmin <= rc2);
-                int flag = 0;
-                if (testers != 0) { // rare (a fraction of a percent of the envs of the benchmark rollout)
-                    // which of its pairs: neighbours k = 1..31 within range at bit k of hm, the antipode k = 32 in ht
-                    // (the same float32 operations as the loop above, hence the same verdicts)
-                    uint32_t hm = 0;
-                    bool ht = false;
-#pragma unroll 1
-                    for (int k = 1; k <= 32; ++k) {
-                        const float rx = f32sub(t[k], mine.x), ry = f32sub(t[128 + k], mine.y), rz = f32sub(t[256 + k], mine.z);
-                        const bool in = f32fma(rz, rz, f32fma(ry, ry, f32mul(rx, rx))) <= rc2;
-                        if (k < 32) hm |= in ? (1u << k) : 0u; else ht = in;
-                    }
-                    const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
-                    flag = MRS_PAIR_ROWS; // several pairs: every lane notes its partners (below)
-                    const int a = __builtin_ctzll(testers), nb = __builtin_popcountll(testers);
-                    if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
-                        const uint32_t hma = (uint32_t)__builtin_amdgcn_readlane((int)hm, a);
-                        if (nb == 1 && hma != 0) {
-                            flag = MRS_PAIR_SINGLE | a | (((a + __builtin_ctz(hma)) & 63) << 8);
-                        } else if (nb == 2 && a < 32 && __builtin_amdgcn_ballot_w64(ht && hm == 0) == testers && (testers >> (a + 32)) == 1ull) {
-                            flag = MRS_PAIR_SINGLE | a | ((a + 32) << 8);
-                        }
-                    }
-                    if (flag == MRS_PAIR_ROWS) {
-                        // the partners of a lane: the ones it tested itself (hm, relative bit k) and the ones that tested it
-                        // (handed over as in the loop above, mirrored into relative bit 64-k), rotated into absolute columns
-                        uint32_t hrh = 0;
-#pragma unroll
-                        for (int k = 1; k < 32; ++k) hrh |= (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), (int)(hm & (1u << k)));
-                        const uint64_t hrel = ((uint64_t)((__builtin_bitreverse32(hrh) << 1) | (ht ? 1u : 0u)) << 32) | hm;
-                        A.pair_rows[(size_t)e * 64 + lane] = lane ? ((hrel << lane) | (hrel >> (64 - lane))) : hrel;
-                    }
-                }
-                if (lane == 0) A.pair_flag[e] = flag;
-            }
-            const uint32_t hi = (__builtin_bitreverse32(hr) << 1) | top; // bit k -> bit 32-k
-            const uint64_t rel = comm_inf ? ~1ull : (((uint64_t)hi << 32) | lo);
-            if (row && KO_KEEP(2)) st<2>(row, (uint64_t)(lane ? ((rel << lane) | (rel >> (64 - lane))) : rel));
+            uint64_t r64;
+            float dmin;
+            adj64_pass(t, mine.x, mine.y, mine.z, thr_s, !comm_inf, want_hit, lane, r64, dmin);
+            if (want_hit) adj64_flag(A, t, mine.x, mine.y, mine.z, lane, e, dmin <= A.pair_rc2);
+            if (row && KO_KEEP(2)) st<2>(row, r64);
         }
     } else {
         bool hit = false;
@@ -514,7 +494,6 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 {
     const DownwashRegs dr = downwash_regs(dc);
     const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
-#if MRS_DPP_HANDOVER
     // Magnitudes are summed and the sign is applied once at the end (-(a + b) == (-a) + (-b) bit for bit).  The terms a lane
     // keeps: float32 partial sums of two per pass, flushed to float64 every four passes.  The terms for the lower quadcopter
     // of a pair travel to it in `trav` (see wave_ror1), k descending; a lane receives 31 of them as one float32 sum.
@@ -548,47 +527,6 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
     }
     dkeep += (double)f32add(keep.x, keep.y);
     return -(dkeep + (double)wave_ror1(trav));
-#else
-    f2 acc = {0.f, 0.f}; // .x: the terms this lane keeps, .y: the terms handed to it -- one packed add per pair
-    float pend = 0.f;
-    double dacc = 0.;
-    // m = |term| of the pair (this lane, lane + k); rz = the neighbour's height above this lane
-    auto deliver = [&](int k, float m, float rz, float d2) {
-        const bool near = d2 < 100.f;                          // delta_xy < 10 (Quadcopter.py:106)
-        const float f_self = (rz > 0.f && near) ? -m : 0.f;    // the neighbour is above: the term is this lane's
-        const float f_other = (rz < 0.f && near) ? -m : 0.f;   // below: the term is the neighbour's (0 when dz == 0)
-        // lane j receives from lane j - k: byte address 4*(lane + 64 - k), the lane index wraps mod 64
-        const float f_in = __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 4 * (64 - k), __float_as_int(f_other)));
-        // the term handed over by lane i-k is added one pair LATE (its cross-lane round trip then overlaps the next
-        // pair's arithmetic); the sums are anchored so that they are formed here and not sunk to the end of the loop,
-        // which would keep all 31 handed-over terms alive (without the anchor two ACTION_TYPEs spill)
-        acc = acc + f2{f_self, pend};
-        asm volatile("" : "+v"(acc));
-        pend = f_in;
-        if ((k & 7) == 0) { dacc += (double)f32add(acc.x, acc.y); acc = f2{0.f, 0.f}; } // short float32 partial sums
-    };
-    auto mag2 = [&](f2 d2, f2 rz) { return downwash_mag2_pk(d2, rz, dr); };
-#pragma unroll
-    for (int k = 1; k < 31; k += 2) {
-        hook(k >> 1);
-        f2 rx, ry, rz;
-        tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
-        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
-        const f2 m = mag2(d2, rz);
-        deliver(k, m.x, rz.x, d2.x);
-        deliver(k + 1, m.y, rz.y, d2.y);
-    }
-    {   // k = 31, and the antipode k = 32, which both ends evaluate (each keeps its own term)
-        f2 rx, ry, rz;
-        tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
-        const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
-        const f2 m = mag2(d2, rz);
-        deliver(31, m.x, rz.x, d2.x);
-        acc = acc + f2{(rz.y > 0.f && d2.y < 100.f) ? -m.y : 0.f, pend};
-        dacc += (double)f32add(acc.x, acc.y);
-    }
-    return dacc;
-#endif
 }
 
 // Quad-quad contact of lane i with one other agent (oracle/mrs_oracle.c:pair_contact, the same float32 operations): the
@@ -1160,7 +1098,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // observation -- instead of waiting at the barrier below.  No gain, 28.0 against 27.9 us: it then runs the
         // tail twice, once for the free-flying and once for the grounded lanes.)
         if (n > 0) { // uniform over the workgroup
-            // The solving wave is the workgroup's critical path (three waves wait for it at the barrier below) but
+            // The solving wave is the workgroup's critical path (the other waves wait for it at the barrier below) but
             // shares its SIMD with three waves of other workgroups that are still in their issue-bound forces
             // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
             // priority lets it issue whenever it is ready.
@@ -1194,24 +1132,39 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             TL(5); // own share of the contact solve
             __syncthreads();
         }
+        auto reload = [&]() {
+            p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
+            q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
+            v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
+            w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
+        };
+        auto finish = [&]() { // pose, state planes, newest observation slice (MRS.py:255-256) of this lane
+            if (doit) {
+                integrate_pose(A.P, p, q, v, w);
+                if (KO_KEEP(1)) store_state(wb, la, T, p, q, v, w);
+            }
+            if (A.b.obs && live && A.n_obs > 0 && KO_KEEP(2))
+                write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
+        };
+        // (Round 3 experiment, removed: the lanes that are not listed for the solve -- 19 out of 20 -- finishing their step
+        // between the two barriers, under the solver wave's serial chain, and the listed ones behind it.  25.9 against 23.4 us
+        // per step: two exec-masked passes over the 13 state stores write partial cache lines instead of whole ones.)
         TL(6); // barrier 2
         SETPRIO(MRS_P_TAIL, MRS_PA_TAIL, MRS_PB_TAIL); // last phase, lowest priority: see MRS_P_* above
-        p[0] = sp[tid]; p[1] = sp[BLOCK + tid]; p[2] = sp[2 * BLOCK + tid];
-        q[0] = sp[3 * BLOCK + tid]; q[1] = sp[4 * BLOCK + tid]; q[2] = sp[5 * BLOCK + tid]; q[3] = sp[6 * BLOCK + tid];
-        v[0] = sp[7 * BLOCK + tid]; v[1] = sp[8 * BLOCK + tid]; v[2] = sp[9 * BLOCK + tid];
-        w[0] = sp[10 * BLOCK + tid]; w[1] = sp[11 * BLOCK + tid]; w[2] = sp[12 * BLOCK + tid];
+        reload();
         // (the mirror image of MRS_LATE_LOADS -- the 13 state stores spread over the passes of the adjacency pair loop
         // instead of one burst ahead of it -- was measured: no gain, 27.0 against 27.0 us per step)
-        if (doit) {
-            integrate_pose(A.P, p, q, v, w);
-            if (KO_KEEP(1)) store_state(wb, la, T, p, q, v, w);
-        }
+        finish();
+        const float fpx = (float)p[0], fpy = (float)p[1], fpz = (float)p[2];
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         TL(7); // pose + store
-        if (A.b.obs && live && A.n_obs > 0 && KO_KEEP(2))
-            write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
         if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
+        // (Round 3 experiment, removed: the N = 64 adjacency pass taken out of this tail and run between the two barriers of the
+        // hand-off on predicted positions -- final for every lane that is not listed -- with the listed agents' rows and columns
+        // put right afterwards, and the solver waves' envs looked after by the waves next in line.  Bit-identical rows; 23.8 us
+        // per step against 23.3 with eight envs per workgroup, 23.0 with four: the "idle" slots of a workgroup in its hand-off
+        // are the other resident workgroup's, there was nothing to fill.)
         if ((A.do_adj || A.pair_flag != nullptr) && KO_KEEP(16)) {
             // (the env index is formed again from an opaque copy of the thread index: kept live from the top of the kernel
             // it was the one register too many across the contact sweeps)
@@ -1220,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             const int e2 = blockIdx.x * AEPB + (n64 ? (t2 >> 6) : el);
             adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
                                          A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
-                                         make_float4((float)p[0], (float)p[1], (float)p[2], 0.f), e2);
+                                         make_float4(fpx, fpy, fpz, 0.f), e2);
         }
         TL(8); // observation + adjacency
 #ifdef MRS_TIMELINE
@@ -1634,7 +1587,7 @@ extern "C" int mrs_params_default(MrsParams *p)
     p->inertia[2] = p->mass / 12.0 * (lx * lx + lx * lx);
     p->lin_damp = (double)0.04f; p->ang_damp = (double)0.04f; p->max_coord_vel = 100.0; p->use_gyro = 1;
     p->ground_z = 0.5; p->friction = 1.5 * 0.5; p->erp = 0.2; p->contact_threshold = 0.02; // plane.urdf:5,24
-    p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
+    p->solver_iters = 6; p->enable_contact = 1; p->pair_contact = 1;
     return 0;
 }
 
@@ -1707,13 +1660,16 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
     // ... as long as that still gives every CU a workgroup: a swarm of fewer than 8 x CUs envs takes the largest workgroup
     // that does (1024 envs on 256 CUs: 256 threads 13.9 us per step, 512: 17.5; 512 envs: 128 threads 13.7, 512: 16.0)
+    // Round 3: with the bodies at rest finished in their own lanes (contact_at_rest) a workgroup lists a dozen bodies, not a
+    // hundred, for its hand-off, and four envs per workgroup (four workgroups per CU) overtake eight: 512 threads 24.7, 256: 24.1,
+    // 128: 24.6 us per step in the benchmark's window (tools/steady_bench.py, first repetition).
     h->sblock = 256;
     if (n_agents == 64) {
         int ncu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         h->sblock = 64;
-        for (int sb = 512; sb >= 128; sb >>= 1)
+        for (int sb = 256; sb >= 128; sb >>= 1)
             if ((n_envs + sb / 64 - 1) / (sb / 64) >= ncu) { h->sblock = sb; break; }
     }
     if (const char *sb = getenv("MRS_STEP_BLOCK")) {

@@ -56,7 +56,7 @@ void orc_params_default(OrcParams *p)
     /* plane.urdf:24 box 30 30 1 centred at the origin, placed at pos 0 (EnvCreator.py:11) */
     p->ground_z = 0.5;
     p->friction = 1.5 * 0.5; /* plane.urdf:5 lateral 1.5 x default link friction 0.5 */
-    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
+    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 6; p->enable_contact = 1; p->pair_contact = 1;
 }
 
 void orc_derived(const OrcParams *p, double out[7])
@@ -534,8 +534,8 @@ static void matTvec(const double R[9], const double v[3], double o[3])
  * cap of the collision cylinder faces the ground,
  * Bullet-style velocity-level rhs (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint),
  * sequential impulses with a friction pyramid along world x/y. */
-/* Diagnostic tap (tools/contact_lab.py, single-threaded runs only): the inputs of every contact problem, 16 doubles each
- * (z, R[9], v[3], w[3]), for offline experiments with the solver. */
+/* Diagnostic tap (tools/contact_lab.py, single-threaded runs only): the inputs of every contact problem, 17 doubles each
+ * (z, R[9], v[3], w[3], the body's address as an identity across steps), for offline experiments with the solver. */
 static double *g_cdump = 0;
 static long g_cdump_cap = 0, g_cdump_n = 0;
 void orc_contact_dump(double *buf, long cap) { g_cdump = buf; g_cdump_cap = cap; g_cdump_n = 0; }
@@ -546,8 +546,8 @@ static void contact_solve(const OrcParams *p, const double pos[3], const double 
     const double bound = sqrt(p->coll_radius * p->coll_radius + p->coll_half_len * p->coll_half_len);
     if (pos[2] - bound - p->contact_threshold > p->ground_z) return;
     if (g_cdump && g_cdump_n < g_cdump_cap) {
-        double *d = g_cdump + 16 * g_cdump_n++;
-        d[0] = pos[2];
+        double *d = g_cdump + 17 * g_cdump_n++;
+        d[0] = pos[2]; d[16] = (double)(size_t)pos;
         for (int k = 0; k < 9; ++k) d[1 + k] = R[k];
         for (int k = 0; k < 3; ++k) { d[10 + k] = v[k]; d[13 + k] = w[k]; }
     }

@@ -36,7 +36,7 @@ def test_params_struct_layout_and_constants():
     # SURVEY.md 8a row P
     assert (p.mass, p.arm, p.kf, p.km) == (0.027, 0.0397, 3.16e-10, 7.94e-12)
     assert (p.gravity, p.dt, p.ctrl_gravity, p.ctrl_dt) == (9.81, 0.01, 9.81, 0.01)
-    assert p.ground_z == 0.5 and p.solver_iters == 10 and p.use_gyro == 1 and p.enable_contact == 1
+    assert p.ground_z == 0.5 and p.solver_iters == 6 and p.use_gyro == 1 and p.enable_contact == 1
     d = native.derived(p)
     assert d["HoverRPM"] == pytest.approx(14475.809152959684, rel=1e-14)
     assert d["GroundEffectHClip"] == pytest.approx(0.0377637, rel=1e-5)

@@ -31,7 +31,7 @@ def capture(E=24, steps=800, keep=100):
     lib.orc_contact_dump.argtypes = [C.POINTER(C.c_double), C.c_long]
     lib.orc_contact_dump_count.restype = C.c_long
     cap = E * N * keep
-    buf = np.zeros((cap, 16))
+    buf = np.zeros((cap, 17))
     a = None
     for t in range(steps):
         if t % 50 == 0:
@@ -582,3 +582,86 @@ def order_study():
 
 if len(sys.argv) > 1 and sys.argv[1] == "order":
     order_study()
+
+
+def warm_study():
+    """Warm start across steps (what Bullet does): the impulses a body's rows ended the previous step with are the start of
+    this step's sweeps.  Bodies are matched across the captured steps by identity; a body without a problem in the step
+    before starts from the equal share."""
+    d = np.load(OUT)
+    ids = d[:, 16]
+    # split into steps: the capture is in step order, ids ascending within a step
+    brk = np.flatnonzero(np.diff(ids) < 0) + 1
+    steps = np.split(np.arange(len(d)), brk)
+    print("%d steps captured" % len(steps))
+    prev = {}
+    hist_w = np.zeros(12, int); hist_c = np.zeros(12, int); errs_w = []; errs_c = []
+    for si, idx in enumerate(steps):
+        P = Prob(d[idx]); act = P.act.any(1)
+        if not act.any():
+            prev = {}; continue
+        sub = idx[act]; P = Prob(d[sub])
+        ref = pgs12(P, 300, tol=0, stag=2.0)
+        l0n = np.zeros((P.M, 4)); l0t = np.zeros((P.M, 4, 2)); have = np.zeros(P.M, bool)
+        for m, b in enumerate(d[sub, 16]):
+            if b in prev:
+                l0n[m], l0t[m] = prev[b]; have[m] = True
+        dvw, dww, usedw, lam = pgs12_warm(P, 10, l0n, l0t, have)
+        dvc, dwc, usedc, _, _ = pgs12(P, 10)
+        prev = {b: (lam[0][m].copy(), lam[1][m].copy()) for m, b in enumerate(d[sub, 16])}
+        if si >= 5:
+            hist_w += np.bincount(usedw, minlength=12)[:12]; hist_c += np.bincount(usedc, minlength=12)[:12]
+            errs_w.append(np.maximum(np.abs(dvw - ref[0]).max(1), 0.06 * np.abs(dww - ref[1]).max(1)))
+            errs_c.append(np.maximum(np.abs(dvc - ref[0]).max(1), 0.06 * np.abs(dwc - ref[1]).max(1)))
+    ew, ec = np.concatenate(errs_w), np.concatenate(errs_c)
+    print("cold (equal share)  sweeps hist %s  err 99%% %.1e 99.9%% %.1e" % (dict((i, int(c)) for i, c in enumerate(hist_c) if c), np.quantile(ec, .99), np.quantile(ec, .999)))
+    print("warm start          sweeps hist %s  err 99%% %.1e 99.9%% %.1e" % (dict((i, int(c)) for i, c in enumerate(hist_w) if c), np.quantile(ew, .99), np.quantile(ew, .999)))
+
+
+def pgs12_warm(P, iters, l0n, l0t, have, tol=1e-7, stag=0.5):
+    M = P.M
+    dv = np.zeros((M, 3)); dw = np.zeros((M, 3))
+    r = P.rk; act = P.act; E3 = np.eye(3)
+    def ang(k, d):
+        return np.einsum("mij,mj->mi", P.Iw, np.cross(r[:, k], np.broadcast_to(d, (M, 3))))
+    an = [ang(k, E3[2]) for k in range(4)]; ax = [ang(k, E3[0]) for k in range(4)]; ay = [ang(k, E3[1]) for k in range(4)]
+    def keff(k, d, a):
+        return 1.0 / (P.im + np.einsum("mi,mi->m", np.cross(r[:, k], np.broadcast_to(d, (M, 3))), a))
+    Kn = [np.where(act[:, k], keff(k, E3[2], an[k]), 0.0) for k in range(4)]
+    Kt = [[np.where(act[:, k], keff(k, E3[0], ax[k]), 0.0), np.where(act[:, k], keff(k, E3[1], ay[k]), 0.0)] for k in range(4)]
+    At = [[ax[k], ay[k]] for k in range(4)]
+    nact = act.sum(1); rsum = np.where(act, P.rhs, 0).sum(1)
+    eq = np.where(nact > 0, P.mass * np.maximum(rsum, 0) / np.maximum(nact, 1) ** 2, 0.0)
+    ln = np.where(have[:, None], l0n, eq[:, None]) * act
+    lt = np.where(have[:, None, None], l0t, 0.0) * act[:, :, None]
+    for k in range(4):
+        dv[:, 2] += ln[:, k] * P.im; dw += an[k] * ln[:, k, None]
+        for a in range(2):
+            dv[:, a] += lt[:, k, a] * P.im; dw += At[k][a] * lt[:, k, a, None]
+    tolv = tol * P.mass * P.g * P.dt
+    done = np.zeros(M, bool); used = np.zeros(M, int); prev = np.full(M, 3e38); moved = np.zeros(M)
+    for it in range(iters):
+        if it % 2 == 0:
+            moved = np.zeros(M)
+        live = ~done
+        for k in range(4):
+            rk = r[:, k]
+            dvn = dv[:, 2] + dw[:, 0] * rk[:, 1] - dw[:, 1] * rk[:, 0]
+            nl = np.maximum(ln[:, k] + Kn[k] * (P.rhs[:, k] - dvn), 0)
+            dl = np.where(live, nl - ln[:, k], 0); ln[:, k] += dl
+            moved = np.maximum(moved, np.abs(dl)); dv[:, 2] += dl * P.im; dw += an[k] * dl[:, None]
+            lim = P.mu * ln[:, k]
+            for a in range(2):
+                vt = (P.v + dv + np.cross(P.w + dw, rk))[:, a]
+                nl = np.clip(lt[:, k, a] - Kt[k][a] * vt, -lim, lim)
+                dl = np.where(live, nl - lt[:, k, a], 0); lt[:, k, a] += dl
+                moved = np.maximum(moved, np.abs(dl)); dv[:, a] += dl * P.im; dw += At[k][a] * dl[:, None]
+        used += live
+        if it % 2 == 1:
+            done |= (moved <= np.maximum(tolv, tol * ln.max(1))) | (moved >= stag * prev)
+            prev = moved.copy()
+    return dv, dw, used, (ln, lt)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "warm":
+    warm_study()
