@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRS_ABI_VERSION 2
+#define MRS_ABI_VERSION 3
 
 /* error codes (negative) */
 #define MRS_E_ARG (-1)        /* bad argument (NULL, size, unsupported N) */
@@ -99,9 +99,11 @@ typedef struct MrsBuffers {
     double *quat;     /* [4][T]  body->world orientation, xyzw                     */
     double *vel;      /* [3][T]  world linear velocity                             */
     double *angvel;   /* [3][T]  world angular velocity                            */
-    float *pid;       /* [18][T] controller memory (QuadControl.py:41-110), float32 planes:
-                         0-2 integral_pos_e, 3-5 d_vel_e, 6-8 integral_vel_e, 9-11 integral_ori_e,
-                         12-14 last_vel_e, 15-17 last_target_vel (NaN = attribute not created yet).
+    float *pid;       /* [5][T][4] controller memory (QuadControl.py:41-110): five planes of 16-byte records (16-byte
+                         aligned; one load and one store instruction per record and step), float32:
+                         0: integral_pos_e xyz, pad      1: d_vel_e xyz, integral_vel_e x
+                         2: integral_vel_e yz, last_vel_e xy      3: last_vel_e z, last_target_vel xyz
+                         4: integral_ori_e xyz, pad      (last_*: NaN = attribute not created yet).
                          The arithmetic is float64 in registers; only the step-to-step carry is float32
                          (measured effect on 1000-step trajectories: < 1e-6, tests/test_gpu_parity.py). */
     float *obs;       /* (E,N,D) newest observation slice, row-major, or NULL      */

@@ -115,14 +115,15 @@ __device__ __forceinline__ void st(T *ptr, T v)
 struct WgBuffers {
     double *pos, *quat;
     vel_t *vel, *angvel;
-    float *pid, *obs, *rpm;
+    float4 *pid;
+    float *obs, *rpm;
     uint64_t *adj;
 };
 __device__ __forceinline__ WgBuffers wg_buffers(const StepArgs &A, size_t wg_base)
 {
     WgBuffers w;
     w.pos = A.b.pos + wg_base; w.quat = A.b.quat + wg_base; w.vel = VELP(A.b.vel) + wg_base; w.angvel = VELP(A.b.angvel) + wg_base;
-    w.pid = A.b.pid ? A.b.pid + wg_base : nullptr;
+    w.pid = A.b.pid ? reinterpret_cast<float4 *>(A.b.pid) + wg_base : nullptr;
     w.rpm = A.b.rpm ? A.b.rpm + wg_base : nullptr;
     w.obs = A.b.obs ? A.b.obs + wg_base * (size_t)A.D : nullptr;
     w.adj = A.b.adj ? A.b.adj + wg_base * (size_t)A.W : nullptr;
@@ -246,6 +247,9 @@ __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, co
     asm volatile("" : "+v"(thr)); // not re-read from the argument segment inside the loop (see adjacency_phase)
     const bool inf = A.comm_inf != 0;
     const f2 mx = splat(me.x), my = splat(me.y), mz = splat(me.z);
+    // the next float above each threshold (finite and positive; a negative range sentinel only moves further from every d2 >= 0)
+    f2 thr_up2 = splat(__uint_as_float(__float_as_uint(thr) + (thr >= 0.f ? 1u : 0u))), rc2_up2 = splat(__uint_as_float(__float_as_uint(rc2) + 1u));
+    asm volatile("" : "+v"(thr_up2), "+v"(rc2_up2));
     for (int wd = 0; wd < A.W; ++wd) {
         const int j0 = wd * 64, jn = min(64, A.N - j0);
         uint32_t half[2] = {0u, 0u}, hhalf[2] = {0u, 0u};
@@ -253,6 +257,10 @@ __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, co
             const uint64_t all = jn == 64 ? ~0ull : ((1ull << jn) - 1ull);
             half[0] = (uint32_t)all; half[1] = (uint32_t)(all >> 32);
         } else if (jn == 64) {
+            // A verdict costs 1.5 instructions (round 2: three -- compare, select, or): d2 <= T  <=>  d2 < T' with T' the next
+            // float above T  <=>  the SIGN BIT of d2 - T' (a subtraction of two different floats never rounds to zero, so the
+            // sign is exact); one packed subtraction gives two signs and v_alignbit_b32 shifts each into the word,
+            // ({word, sign} >> 31).  The first verdict ends up in the top bit: one v_bfrev per word puts them in column order.
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 uint32_t bits = 0, hb = 0;
@@ -261,10 +269,16 @@ __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, co
                     const int j = j0 + hh * 32 + jj;
                     const f2 dx = pk_sub(mx, f2{tx[j], tx[j + 1]}), dy = pk_sub(my, f2{ty[j], ty[j + 1]}), dz = pk_sub(mz, f2{tz[j], tz[j + 1]});
                     const f2 d2 = pk_fma(dz, dz, pk_fma(dy, dy, pk_mul(dx, dx)));
-                    bits |= (d2.x <= thr ? (1u << jj) : 0u) | (d2.y <= thr ? (2u << jj) : 0u);
-                    hb |= (d2.x <= rc2 ? (1u << jj) : 0u) | (d2.y <= rc2 ? (2u << jj) : 0u);
+                    const f2 st = pk_sub(d2, thr_up2);
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(st.x), 31);
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(st.y), 31);
+                    if (want_hit) {
+                        const f2 sc = pk_sub(d2, rc2_up2);
+                        hb = __builtin_amdgcn_alignbit(hb, __float_as_uint(sc.x), 31);
+                        hb = __builtin_amdgcn_alignbit(hb, __float_as_uint(sc.y), 31);
+                    }
                 }
-                half[hh] = bits; hhalf[hh] = hb;
+                half[hh] = __builtin_bitreverse32(bits); hhalf[hh] = __builtin_bitreverse32(hb);
             }
         } else { // the last, partial word of an N that is not a multiple of 64
             for (int jj = 0; jj < jn; ++jj) {
@@ -875,22 +889,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             if (ACT == MRS_ACT_TARGET_VEL || ACT == MRS_ACT_TARGET_POS) {
                 Observed o0;
                 observe<false, false>(p, q, v, w, o0);
-                float *g = wb.pid + la;
+                // controller memory: 16-byte records (MrsBuffers.pid), one load / store instruction per record
+                float4 *g = wb.pid + la;
                 if (ACT == MRS_ACT_TARGET_POS) {
-                    s.ipx = g[0]; s.ipy = g[T]; s.ipz = g[2 * T];
+                    const float4 r0 = g[0];
+                    s.ipx = r0.x; s.ipy = r0.y; s.ipz = r0.z;
                     ta = pos_control_accel(P, s, o0, act[0], act[1], act[2]);
-                    g[0] = (float)s.ipx; g[T] = (float)s.ipy; g[2 * T] = (float)s.ipz;
+                    g[0] = make_float4((float)s.ipx, (float)s.ipy, (float)s.ipz, 0.f);
                 } else {
-                    s.dvx = g[3 * T]; s.dvy = g[4 * T]; s.dvz = g[5 * T];
-                    s.ivx = g[6 * T]; s.ivy = g[7 * T]; s.ivz = g[8 * T];
-                    s.lvx = g[12 * T]; s.lvy = g[13 * T]; s.lvz = g[14 * T];
-                    s.ltx = g[15 * T]; s.lty = g[16 * T]; s.ltz = g[17 * T];
+                    const float4 r1 = g[T], r2 = g[2 * T], r3 = g[3 * T];
+                    s.dvx = r1.x; s.dvy = r1.y; s.dvz = r1.z;
+                    s.ivx = r1.w; s.ivy = r2.x; s.ivz = r2.y;
+                    s.lvx = r2.z; s.lvy = r2.w; s.lvz = r3.x;
+                    s.ltx = r3.y; s.lty = r3.z; s.ltz = r3.w;
                     ta = vel_control_accel(P, s, o0, act[0], act[1], act[2]);
                     if (KO_KEEP(4)) {
-                    st<4>(g + 3 * T, (float)s.dvx); st<4>(g + 4 * T, (float)s.dvy); st<4>(g + 5 * T, (float)s.dvz);
-                    st<4>(g + 6 * T, (float)s.ivx); st<4>(g + 7 * T, (float)s.ivy); st<4>(g + 8 * T, (float)s.ivz);
-                    st<4>(g + 12 * T, s.lvx); st<4>(g + 13 * T, s.lvy); st<4>(g + 14 * T, s.lvz);
-                    st<4>(g + 15 * T, s.ltx); st<4>(g + 16 * T, s.lty); st<4>(g + 17 * T, s.ltz);
+                        g[T] = make_float4((float)s.dvx, (float)s.dvy, (float)s.dvz, (float)s.ivx);
+                        g[2 * T] = make_float4((float)s.ivy, (float)s.ivz, s.lvx, s.lvy);
+                        g[3 * T] = make_float4(s.lvz, s.ltx, s.lty, s.ltz);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -909,8 +925,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             } else observe<true, true>(p, q, v, w, ob);
             TL(21); // read-back + rotation matrices
             if (NEEDS_PID) {
-                float *g = wb.pid + la;
-                s.iox = g[9 * T]; s.ioy = g[10 * T]; s.ioz = g[11 * T];
+                float4 *g = wb.pid + la;
+                const float4 r4 = g[4 * T];
+                s.iox = r4.x; s.ioy = r4.y; s.ioz = r4.z;
                 if (ACT == MRS_ACT_TARGET_ORI) { // Quadcopter.py:63-65
                     const M3 Rt = euler_to_matrix((double)act[0], (double)act[1], (double)act[2]);
                     attitude_control(P, A.rc, s, Rt, R, ob, v3(0., 0., 9.81), 9.81, 1.0 / 9.81, rpm);
@@ -918,7 +935,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     if (ACT == MRS_ACT_TARGET_ACCEL) ta = v3((double)act[0], (double)act[1], (double)act[2]);
                     accel_control(P, A.rc, s, ta, R, ob, rpm);
                 }
-                if (KO_KEEP(4)) { st<4>(g + 9 * T, (float)s.iox); st<4>(g + 10 * T, (float)s.ioy); st<4>(g + 11 * T, (float)s.ioz); }
+                if (KO_KEEP(4)) g[4 * T] = make_float4((float)s.iox, (float)s.ioy, (float)s.ioz, 0.f);
             } else if (ACT == MRS_ACT_SET_CONTROL) {
                 set_control(P, act[0], act[1], act[2], act[3], rpm);
             } else {
@@ -1119,7 +1136,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/sweeps_probe.py); the run's physics is void
                     float dg[2] = {0.f, 0.f};
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw, dg);
-                    if (wb.pid) { wb.pid[b] = dg[0]; (wb.pid + T)[b] = dg[1]; }
+                    if (wb.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
 #else
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw);
 #endif
@@ -1332,8 +1349,10 @@ __global__ void k_pid_reset(MrsBuffers b, const uint8_t *mask, int N, size_t T)
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= T) return;
     if (mask && !mask[a / N]) return;
-    for (int k = 0; k < 12; ++k) b.pid[k * T + a] = 0.0f;
-    for (int k = 12; k < 18; ++k) b.pid[k * T + a] = __builtin_nanf("");
+    float4 *g = reinterpret_cast<float4 *>(b.pid) + a;
+    const float nan = __builtin_nanf(""); // last_vel_e / last_target_vel: "attribute not created yet" (QuadControl.py:55-59)
+    g[0] = make_float4(0.f, 0.f, 0.f, 0.f); g[T] = make_float4(0.f, 0.f, 0.f, 0.f); g[2 * T] = make_float4(0.f, 0.f, nan, nan);
+    g[3 * T] = make_float4(nan, nan, nan, nan); g[4 * T] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------ spawn

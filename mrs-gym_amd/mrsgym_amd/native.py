@@ -101,7 +101,7 @@ def lib():
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
-        if L.mrs_abi_version() != 2:
+        if L.mrs_abi_version() != 3:
             raise MrsNativeError("libmrs_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -190,8 +190,9 @@ class SwarmShard:
         self.quat[3] = 1.0
         self.vel = torch.zeros(3, self.T, **f64)
         self.angvel = torch.zeros(3, self.T, **f64)
-        self.pid = torch.zeros(18, self.T, dtype=torch.float32, device=device)
-        self.pid[12:] = float("nan")          # last_vel_e / last_target_vel "attribute not created yet"
+        self.pid = torch.zeros(5, self.T, 4, dtype=torch.float32, device=device)   # five planes of 16-byte records (include/mrs_hip.h)
+        self.pid[2, :, 2:] = float("nan")     # last_vel_e / last_target_vel "attribute not created yet"
+        self.pid[3] = float("nan")
         self.status = torch.zeros(self.E, dtype=torch.int32, device=device)
         self.rpm = torch.zeros(4, self.T, dtype=torch.float32, device=device) if want_rpm else None
         self.version = 0                      # bumped by everything that changes the state (sensor caches key on it)

@@ -411,7 +411,7 @@ def test_reset_envs_touches_only_the_selected_envs():
         assert float(Xk[mask.cuda()][:, k, :, 3:].abs().max()) == 0.0
     for name in ("pos", "quat", "vel", "angvel", "pid"):
         a, b = getattr(env.shard, name), getattr(ref.shard, name)
-        va, vb = a.view(a.shape[0], E, N), b.view(b.shape[0], E, N)
+        va, vb = a.view(a.shape[0], E, N, -1), b.view(b.shape[0], E, N, -1)    # planes of scalars, or of 16-byte records (pid)
         assert torch.equal(va[:, keep.cuda()], vb[:, keep.cuda()]), name          # state + controller memory intact
     assert torch.equal(env.env_steps().cpu(), torch.tensor([15, 0, 15, 0]))
     # next step: A history of the reset envs is [A_new, 0, 0]; the others carry on exactly like the reference run

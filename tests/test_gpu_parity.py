@@ -403,7 +403,7 @@ def test_full_size_bench_workload_properties():
     for t in range(300):
         sh.step(torch.from_numpy(one(acts(t))).cuda(), "set_target_vel", obs_out=obs, adj_out=adj, comm_range=R)
     for name in ("pos", "quat", "vel", "angvel", "pid"):
-        v = getattr(sh, name); v = v.view(v.shape[0], E, N)
+        v = getattr(sh, name); v = v.view(v.shape[0], E, N, -1)
         assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(v[:, :1]).expand_as(v)), name
     assert torch.equal(obs, obs[:1].expand_as(obs)) and torch.equal(adj, adj[:1].expand_as(adj))
     assert float(sh.pos[2].min()) < 0.6                                    # the copies did reach the ground

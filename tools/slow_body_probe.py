@@ -17,8 +17,8 @@ obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torc
 def step(t): sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
 for t in range(800): step(t)
 def probe(t):
-    sh.pid[0:2].zero_(); step(t); torch.cuda.synchronize()
-    return sh.pid[0].cpu().numpy().copy(), sh.pid[1].cpu().numpy().copy()
+    sh.pid[0].zero_(); step(t); torch.cuda.synchronize()
+    return sh.pid[0, :, 0].cpu().numpy().copy(), sh.pid[0, :, 1].cpu().numpy().copy()
 c0, r0 = probe(800)
 q = sh.quat.cpu().numpy(); w = sh.angvel.cpu().numpy(); v = sh.vel.cpu().numpy(); p = sh.pos.cpu().numpy()
 c1, r1 = probe(801)

@@ -18,10 +18,10 @@ obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torc
 for t in range(800):
     sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
 torch.cuda.synchronize()
-sh.pid[0:2].zero_()
+sh.pid[0].zero_()
 sh.step_ptr(table[16], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)   # planes 0-2 (integral_pos_e) are not used by set_target_vel
 torch.cuda.synchronize()
-conv = sh.pid[0].cpu().numpy(); ran = sh.pid[1].cpu().numpy()
+conv = sh.pid[0, :, 0].cpu().numpy(); ran = sh.pid[0, :, 1].cpu().numpy()
 solved = ran > 0
 print("bodies solved: %d of %d (%.1f %%)" % (solved.sum(), E * N, 100 * solved.mean()))
 print("sweeps run by their wave: ", {int(k): int((ran[solved] == k).sum()) for k in np.unique(ran[solved])})
