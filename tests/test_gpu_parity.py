@@ -152,6 +152,37 @@ def test_north_star_tolerance_1000_steps(atype):
         assert sw.pos[..., 2].min() > 0.7, "scenario was meant to stay in free flight"
 
 
+def test_north_star_tolerance_independent_targets():
+    """The same 1e-4 / 1000-step bar with INDEPENDENT per-agent velocity targets (coherent=False: every quadcopter its own
+    U[-0.4, 0.4]^3 m/s target, resampled every 50 steps, vertical sign alternating so that nobody reaches the ground), spawn
+    yaw up to +-1.0 rad, on a 2 m grid so that nobody passes through a neighbour's downwash cone.  Measured (tools/ns_probe.py):
+    3e-7 here; with |yaw| <= 1.2 the same run is at 1e-2 after 1000 steps without any body touching the ground -- the
+    reference's attitude loop (world-frame angular velocity in the body-rate D term, Quadcopter.py:54) is marginally stable
+    there and amplifies the float32-level differences between the two implementations (profiles/r03_readme_stability.txt:
+    for |yaw| up to pi/2 one README quadcopter in ten no longer holds its target at all).  So the 1e-4 claim is made for
+    |yaw| <= 1.0, formation or not; beyond that it is chaos amplification, not an implementation difference."""
+    import mrsgym_amd
+    E, N, atype = 4, 64, "set_target_vel"
+    pos, eul = grid_spawn(E, N, seed=0, yaw_range=1.0, pitch=2.0)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=eul, vel=z.astype(np.float64), angvel=z.astype(np.float64))
+    acts = ActionStream(atype, E, N, pos, seed=11, coherent=False)
+    worst = {}
+    for t in range(1000):
+        a = (acts(t) * 0.4).astype(np.float32)
+        a[..., 2] = (1 if (t // 50) % 2 == 0 else -1) * np.abs(a[..., 2])
+        sh.step(torch.from_numpy(a).cuda(), atype)
+        sw.step(a, atype)
+        if t % 100 == 99:
+            errs = _compare(sh, sw, 1e-4, "independent targets t=%d" % t)
+            worst = {k: max(v, worst.get(k, 0)) for k, v in errs.items()}
+    print("north-star parity, independent targets", worst)
+    assert sw.pos[..., 2].min() > 0.6, "scenario was meant to stay in free flight"
+
+
 def test_adjacency_golden_bit_exact(golden_dir):
     import mrsgym_amd
     d = np.load(os.path.join(golden_dir, "F3_adjacency.npz"))
