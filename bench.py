@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--no-dense-a", action="store_true", help="skip the extra dense-adjacency leg (N=1)")
     ap.add_argument("--dense-a", action="store_true", help="materialise the float32 (E,K+1,N,N) adjacency the reference returns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-double-buffer", action="store_true", help="skip the two-half-swarms-on-two-streams leg (N=1)")
     args = ap.parse_args()
 
     import mrsgym_amd
@@ -146,17 +147,18 @@ def main():
     base = rank * E
     pos, eul = grid_spawn(E, N, env_base=base)
 
-    def make_env(a_format):
-        env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
-                              RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos),
-                              A_FORMAT=a_format, ENV_INDEX_BASE=base, DEVICE=str(dev), CHECK_NAN="lazy",
+    def make_env(a_format, lo=0, hi=None):
+        hi = E if hi is None else hi
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=hi - lo, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
+                              RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos[lo:hi]),
+                              A_FORMAT=a_format, ENV_INDEX_BASE=base + lo, DEVICE=str(dev), CHECK_NAN="lazy",
                               HISTORY_SLOTS=int(os.environ.get("MRS_BENCH_HISTORY_SLOTS", "0")))
-        env.reset(ori=torch.from_numpy(eul))
+        env.reset(ori=torch.from_numpy(eul[lo:hi]))
         return env
 
     acts = ActionStream(ATYPE, E, N, pos, seed=1000 + rank)
     total = args.warmup + args.steps
-    n_regions = 2 if (world > 1 or not args.no_dense_a) else 1
+    n_regions = 3 if world == 1 else 2
     table = [torch.from_numpy(acts(50 * k)).to(dev) for k in range((args.rollin + n_regions * total) // 50 + 2)]
     # Device warm-up on a SCRATCH swarm, run immediately before every measured swarm starts (its roll-in follows with no
     # host-side gap): after the GPU has been idle for tens of milliseconds -- process start, but also the allocations
@@ -278,6 +280,42 @@ def main():
             extra["dense_a"] = {"value": agent_steps / d_elapsed, "unit": "agent-steps/s", "ms_per_step": d_elapsed / args.steps * 1e3,
                                 "what": "same K steps with info['A'] as the dense float32 (E,K+1,N,N) tensor the reference returns "
                                         "(516 B per agent-step algorithmic, SURVEY.md 8d) instead of bit-packed rows"}
+            del denv
+        if not args.no_double_buffer and E % 2 == 0:
+            # BESIDE `value`, never instead of it: the same swarm as two half-swarms on two streams, each stepping on its own
+            # (the EnvPool / Sample-Factory pattern: a closed loop may use it, the policy for half A runs while half B steps).
+            # The two kernels overlap, half A's tail and hand-off bubbles under half B's forces phase and vice versa.
+            # Driven at the C-ABI level (SwarmShard.step_ptr, fixed observation / adjacency buffers): two env.step() calls per round
+            # cost 2 x ~13 us of Python, more than the two kernels take (measured: 29.5 us per round through env.step()).
+            from mrsgym_amd.native import ACT as _ACT
+            halves = []
+            for lo, hi in ((0, E // 2), (E // 2, E)):
+                sh = mrsgym_amd.SwarmShard(hi - lo, N, dev)
+                zz = np.zeros((hi - lo, N, 3), np.float32)
+                sh.set_state(pos=pos[lo:hi], ori=eul[lo:hi], vel=zz, angvel=zz)
+                halves.append((sh, torch.zeros(hi - lo, N, sh.D, device=dev), torch.zeros(hi - lo, N, sh.W, dtype=torch.int64, device=dev),
+                               [t_[lo:hi].contiguous() for t_ in table], torch.cuda.Stream(device=dev)))
+            at = _ACT[ATYPE]
+
+            def round_(t):
+                for sh, o_, a_, tb, st_ in halves:
+                    with torch.cuda.stream(st_):
+                        sh.step_ptr(tb[t // 50], at, o_.data_ptr(), a_.data_ptr(), COMM_RANGE)
+            torch.cuda.synchronize()
+            for t in range(args.rollin + args.warmup):
+                round_(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(args.rollin + args.warmup, args.rollin + total):
+                round_(t)
+            torch.cuda.synchronize()
+            db_elapsed = time.perf_counter() - t0
+            extra["double_buffered"] = {"value": agent_steps / db_elapsed, "unit": "agent-steps/s", "ms_per_step": db_elapsed / args.steps * 1e3,
+                                        "what": "two half-swarms of %d envs on two HIP streams, free-running (each half's step t+1 follows its own "
+                                                "step t; the halves are never joined), driven through the C-ABI (mrs_step) with fixed output buffers: "
+                                                "K rounds = K steps of both halves; reported beside the synchronous `value`, which is one launch "
+                                                "over all envs per env.step()" % (E // 2)}
+            del halves
     else:
         # `value`: BASELINE config 5 / north_star -- every step followed by the RCCL all-gather of the joint observation
         elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, True)

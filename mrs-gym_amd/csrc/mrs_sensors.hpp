@@ -170,93 +170,123 @@ __device__ __forceinline__ D3 cyl_support(const Cyl &s, D3 d, double rc, double 
     if (n > 1e-300) r = r + (rc / n) * rad;
     return r;
 }
+// The simplex lives in REGISTERS (round 3; round 2 indexed its arrays with run-time indices -- "add the point at s.n",
+// "keep points idx[k]" -- which forced the whole structure, and its three working copies, into 1 312 bytes of scratch per
+// lane): every index below is a compile-time constant after inlining and unrolling, the one run-time position (where the
+// new point goes) is a select per slot, the support point on B is not kept (b = a - w), the roll-back copy of the previous
+// simplex is replaced by the previous closest points, and the tetrahedron case chooses its face in a first pass over the
+// four faces and builds it in a second instead of keeping the best candidate simplex.
 struct Simplex {
-    D3 w[4], a[4], b[4];
+    D3 w[4], a[4]; // w = a - b (Minkowski difference), a = support point on A
     double l[4];
     int n;
 };
-__device__ inline void sx_keep(Simplex &s, int i0, int i1, int i2, int n, double l0, double l1, double l2)
+template <int I0, int I1, int I2, int NK>
+__device__ __forceinline__ void sx_keep(Simplex &s, double l0, double l1, double l2)
 {
-    const int idx[3] = {i0, i1, i2};
-    const double l[3] = {l0, l1, l2};
-    const Simplex t = s;
-    for (int k = 0; k < n; ++k) { s.w[k] = t.w[idx[k]]; s.a[k] = t.a[idx[k]]; s.b[k] = t.b[idx[k]]; s.l[k] = l[k]; }
-    s.n = n;
+    const D3 w0 = s.w[I0], w1 = s.w[I1], w2 = s.w[I2], a0 = s.a[I0], a1 = s.a[I1], a2 = s.a[I2];
+    s.w[0] = w0; s.a[0] = a0; s.l[0] = l0;
+    if (NK > 1) { s.w[1] = w1; s.a[1] = a1; s.l[1] = l1; }
+    if (NK > 2) { s.w[2] = w2; s.a[2] = a2; s.l[2] = l2; }
+    s.n = NK;
 }
-__device__ inline void sx_segment(Simplex &s)
+__device__ __forceinline__ void sx_segment(Simplex &s)
 {
     const D3 A = s.w[0], ab = s.w[1] - A;
     const double t = -dot(A, ab), dn = dot(ab, ab);
     if (t <= 0 || dn <= 0) { s.n = 1; s.l[0] = 1; return; }
-    if (t >= dn) { sx_keep(s, 1, 0, 0, 1, 1, 0, 0); return; }
+    if (t >= dn) { sx_keep<1, 0, 0, 1>(s, 1, 0, 0); return; }
     s.l[1] = t / dn; s.l[0] = 1 - s.l[1];
 }
-__device__ inline void sx_triangle(Simplex &s)
+__device__ __forceinline__ void sx_triangle(Simplex &s)
 {
     const D3 a = s.w[0], b = s.w[1], c = s.w[2], ab = b - a, ac = c - a, ap = -1.0 * a;
     const double d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0 && d2 <= 0) { sx_keep(s, 0, 0, 0, 1, 1, 0, 0); return; }
+    if (d1 <= 0 && d2 <= 0) { sx_keep<0, 0, 0, 1>(s, 1, 0, 0); return; }
     const D3 bp = -1.0 * b;
     const double d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0 && d4 <= d3) { sx_keep(s, 1, 0, 0, 1, 1, 0, 0); return; }
+    if (d3 >= 0 && d4 <= d3) { sx_keep<1, 0, 0, 1>(s, 1, 0, 0); return; }
     const double vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); sx_keep(s, 0, 1, 0, 2, 1 - v, v, 0); return; }
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); sx_keep<0, 1, 0, 2>(s, 1 - v, v, 0); return; }
     const D3 cp = -1.0 * c;
     const double d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0 && d5 <= d6) { sx_keep(s, 2, 0, 0, 1, 1, 0, 0); return; }
+    if (d6 >= 0 && d5 <= d6) { sx_keep<2, 0, 0, 1>(s, 1, 0, 0); return; }
     const double vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); sx_keep(s, 0, 2, 0, 2, 1 - w, w, 0); return; }
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); sx_keep<0, 2, 0, 2>(s, 1 - w, w, 0); return; }
     const double va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); sx_keep(s, 1, 2, 0, 2, 1 - w, w, 0); return; }
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); sx_keep<1, 2, 0, 2>(s, 1 - w, w, 0); return; }
     const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
     s.l[0] = 1 - v - w; s.l[1] = v; s.l[2] = w;
 }
-__device__ inline D3 sx_point(const Simplex &s)
+__device__ __forceinline__ D3 sx_point(const Simplex &s)
 {
     D3 p = mk(0, 0, 0);
-    for (int k = 0; k < s.n; ++k) p = p + s.l[k] * s.w[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < s.n) p = p + s.l[k] * s.w[k];
     return p;
 }
-__device__ inline bool sx_tetra(Simplex &s)
+// face F of the tetrahedron (points I0, I1, I2; the fourth is IO): is the origin on its outer side, and if so how far is
+// the closest point of the face (squared)?  build = true: also leave that face's reduced simplex in s.
+template <int I0, int I1, int I2, int IO, bool BUILD>
+__device__ __forceinline__ bool sx_face(Simplex &s, double &dd)
 {
-    const int F[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
-    const int O[4] = {3, 1, 2, 0};
-    Simplex best = s;
+    const D3 a = s.w[I0], b = s.w[I1], c = s.w[I2], d = s.w[IO];
+    const D3 n = cross(b - a, c - a);
+    const double so = dot(-1.0 * a, n), sd = dot(d - a, n);
+    if (!(so * sd < 0 || sd == 0)) return false;
+    Simplex t = s;
+    sx_keep<I0, I1, I2, 3>(t, 0, 0, 0);
+    sx_triangle(t);
+    const D3 q = sx_point(t);
+    dd = dot(q, q);
+    if (BUILD) s = t;
+    return true;
+}
+__device__ __forceinline__ bool sx_tetra(Simplex &s)
+{
+    // faces {0,1,2}, {0,2,3}, {0,3,1}, {1,3,2} with their opposite points 3, 1, 2, 0; the first face with the smallest
+    // distance wins (strict <, as the oracle's loop)
+    double dd[4] = {0, 0, 0, 0};
+    bool out[4];
+    out[0] = sx_face<0, 1, 2, 3, false>(s, dd[0]);
+    out[1] = sx_face<0, 2, 3, 1, false>(s, dd[1]);
+    out[2] = sx_face<0, 3, 1, 2, false>(s, dd[2]);
+    out[3] = sx_face<1, 3, 2, 0, false>(s, dd[3]);
+    int best = -1;
     double bd = -1;
-    bool outside_any = false;
-    for (int f = 0; f < 4; ++f) {
-        const D3 a = s.w[F[f][0]], b = s.w[F[f][1]], c = s.w[F[f][2]], d = s.w[O[f]];
-        const D3 n = cross(b - a, c - a);
-        const double so = dot(-1.0 * a, n), sd = dot(d - a, n);
-        if (so * sd < 0 || sd == 0) {
-            outside_any = true;
-            Simplex t = s;
-            sx_keep(t, F[f][0], F[f][1], F[f][2], 3, 0, 0, 0);
-            sx_triangle(t);
-            const D3 q = sx_point(t);
-            const double dd = dot(q, q);
-            if (bd < 0 || dd < bd) { bd = dd; best = t; }
-        }
-    }
-    if (!outside_any) return true;
-    s = best;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        if (out[f] && (bd < 0 || dd[f] < bd)) { bd = dd[f]; best = f; }
+    if (best < 0) return true; // the origin is inside
+    double unused;
+    if (best == 0) sx_face<0, 1, 2, 3, true>(s, unused);
+    else if (best == 1) sx_face<0, 2, 3, 1, true>(s, unused);
+    else if (best == 2) sx_face<0, 3, 1, 2, true>(s, unused);
+    else sx_face<1, 3, 2, 0, true>(s, unused);
     return false;
 }
 __device__ inline double gjk_cyl_cyl(const Cyl &A, const Cyl &B, double rc, double hl, D3 &pa, D3 &pb)
 {
     Simplex s;
     s.n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.w[k] = mk(0, 0, 0); s.a[k] = mk(0, 0, 0); s.l[k] = 0; }
     D3 v = A.c - B.c;
     if (dot(v, v) < 1e-24) v = mk(1, 0, 0);
+    D3 ca = mk(0, 0, 0), cb = mk(0, 0, 0); // closest points of the current simplex (what a roll-back returns to)
     for (int it = 0; it < 64; ++it) {
         const D3 sa = cyl_support(A, -1.0 * v, rc, hl), sb = cyl_support(B, v, rc, hl), w = sa - sb;
         const double vv = dot(v, v);
         if (s.n > 0 && vv - dot(v, w) <= 1e-14 * vv + 1e-30) break;
         bool dup = false;
-        for (int k = 0; k < s.n; ++k) dup |= (s.w[k].x == w.x && s.w[k].y == w.y && s.w[k].z == w.z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dup |= (k < s.n) && (s.w[k].x == w.x && s.w[k].y == w.y && s.w[k].z == w.z);
         if (dup) break;
-        const Simplex prev = s;
-        s.w[s.n] = w; s.a[s.n] = sa; s.b[s.n] = sb; s.n++;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k == s.n) { s.w[k] = w; s.a[k] = sa; }
+        s.n++;
         bool inside = false;
         if (s.n == 1) s.l[0] = 1;
         else if (s.n == 2) sx_segment(s);
@@ -271,14 +301,17 @@ __device__ inline double gjk_cyl_cyl(const Cyl &A, const Cyl &B, double rc, doub
             return 0.0;
         }
         const D3 vn = sx_point(s);
-        if (prev.n > 0 && dot(vn, vn) >= vv) { s = prev; break; }
+        if (it > 0 && dot(vn, vn) >= vv) break; // no progress: the previous simplex's closest points stand
+        D3 a = mk(0, 0, 0), b = mk(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < s.n) { a = a + s.l[k] * s.a[k]; b = b + s.l[k] * (s.a[k] - s.w[k]); }
+        ca = a; cb = b;
         v = vn;
         if (dot(v, v) < 1e-24) break;
     }
-    D3 a = mk(0, 0, 0), b = mk(0, 0, 0);
-    for (int k = 0; k < s.n; ++k) { a = a + s.l[k] * s.a[k]; b = b + s.l[k] * s.b[k]; }
-    pa = a; pb = b;
-    const D3 ab = a - b;
+    pa = ca; pb = cb;
+    const D3 ab = ca - cb;
     const double d = sqrt(dot(ab, ab));
     return d < 1e-12 ? 0.0 : d;
 }

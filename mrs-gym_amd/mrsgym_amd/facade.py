@@ -119,10 +119,13 @@ class QuadView:
     def get_contact_points(self, other=None, body=False):  # Object.py:100-116
         """Objects within the contact threshold of this quadcopter (MrsParams.contact_threshold, Bullet's contact
         breaking threshold): one point per touching object -- the closest pair.  'normal force' is not retained by the
-        fused step (its impulses live in registers): zeros.  One env only; batched envs use Environment.proximity()."""
+        fused step (its impulses live in registers): zeros.  Batched envs (N_ENVS > 1): the same content as PADDED tensors,
+        'object' (E,M) int64 object indices (quadcopter index, N = the ground, -1 = padding), 'pos' (E,M,3), 'normal force'
+        (E,M,3), 'distance' (E,M) (+inf padding) and 'count' (E,) valid entries per env, M = N; entries in ascending object index,
+        as the one-env form lists them."""
         sh = self.env._mrs.shard
         if sh.E != 1:
-            raise NotImplementedError("get_contact_points returns ragged lists: with N_ENVS > 1 use env.proximity() / env.collisions()")
+            return self._contact_points_batched(other, body)
         dist, ps, po = self.env.proximity(points=True)
         thr = float(sh.params.contact_threshold)
         d = dist[self._i].clone()
@@ -141,6 +144,35 @@ class QuadView:
         return {'object': [self.env.object_by_index(int(j)) for j in idx.tolist()], 'pos': pts,
                 'normal force': torch.zeros(idx.numel(), 3, device=pts.device), 'distance': d[idx]}
 
+    def _padded(self, keep, d):
+        """keep (E,K) bool -> (order (E,K): the kept columns first, ascending, then the rest; count (E,))"""
+        order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices
+        return order, keep.sum(1)
+
+    def _contact_points_batched(self, other, body):
+        sh = self.env._mrs.shard
+        dist, ps, po = self.env.proximity(points=True)             # (E,N,N+1), (E,N,N+1,3) x2
+        thr = float(sh.params.contact_threshold)
+        d = dist[:, self._i].clone()                                # (E,N+1)
+        d[:, self._i] = float('inf')
+        if other is not None:
+            j = other.uid if not isinstance(other, int) else other
+            only = torch.zeros(d.shape[1], dtype=torch.bool, device=d.device); only[j] = True
+            d = torch.where(only, d, torch.full_like(d, float('inf')))
+        keep = d <= thr
+        order, count = self._padded(keep, d)
+        M = sh.N                                                    # at most N - 1 quadcopters + the ground
+        order = order[:, :M]
+        valid = torch.arange(M, device=d.device)[None, :] < count[:, None]
+        pts = torch.gather(ps[:, self._i], 1, order[:, :, None].expand(-1, -1, 3))
+        if body:
+            Rm, p = self.env.get_ori(mat=True)[:, self._i], self.env.get_pos()[:, self._i]
+            pts = torch.einsum('eji,emj->emi', Rm, pts - p[:, None])
+        zero = torch.zeros_like(pts)
+        return {'object': torch.where(valid, order, torch.full_like(order, -1)), 'pos': torch.where(valid[:, :, None], pts, zero),
+                'normal force': zero, 'distance': torch.where(valid, torch.gather(d, 1, order), torch.full_like(d[:, :M], float('inf'))),
+                'count': count}
+
     def collision(self):  # Object.py:136-137
         c = self.env.collisions()
         return bool(c[self._i]) if self.env._mrs.shard.E == 1 else c[:, self._i]
@@ -150,7 +182,19 @@ class QuadView:
         (the reference's own two tests; it lists the quadcopter itself too, its AABB overlaps and its distance is 0)."""
         sh = self.env._mrs.shard
         if sh.E != 1:
-            raise NotImplementedError("get_closest_objects returns object lists: with N_ENVS > 1 use env.proximity(max_dist=radius)")
+            # batched envs: {'object': (E,M) int64 object indices in the one-env form's order (quadcopters ascending, then the
+            # ground = N), -1 padded, M = N + 1; 'count': (E,)}
+            dist = self.env.proximity()                                 # (E,N,N+1)
+            pos = self.env.get_pos()                                    # (E,N,3)
+            bound = float((sh.params.coll_radius ** 2 + sh.params.coll_half_len ** 2) ** 0.5)
+            me = pos[:, self._i]
+            box = ((pos - me[:, None]).abs() <= radius + bound).all(-1)
+            keep_q = box & (dist[:, self._i, :sh.N] <= radius)
+            keep_g = (me[:, 2] - radius <= float(sh.params.ground_z)) & (dist[:, self._i, sh.N] <= radius)
+            keep = torch.cat([keep_q, keep_g[:, None]], 1)
+            order, count = self._padded(keep, None)
+            valid = torch.arange(sh.N + 1, device=keep.device)[None, :] < count[:, None]
+            return {'object': torch.where(valid, order, torch.full_like(order, -1)), 'count': count}
         dist = self.env.proximity()
         pos = self.env.get_pos()
         bound = float((sh.params.coll_radius ** 2 + sh.params.coll_half_len ** 2) ** 0.5)

@@ -151,3 +151,42 @@ def test_vectorised_collision_reward_over_many_envs():
     assert on_ground.float().mean() > 0.5                                 # most of them landed ...
     assert torch.equal(env.get_env().collisions(ground=True) | ~on_ground, torch.ones_like(on_ground))   # ... and report it
     assert total < 0
+
+
+def test_batched_contact_points_and_closest_objects_match_the_one_env_forms():
+    """Object.get_contact_points / get_closest_objects (Object.py:100-116, :140-147) with N_ENVS > 1: padded tensors + counts,
+    env by env the content of the one-env (list) forms."""
+    import mrsgym_amd
+    E, N = 5, 6
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([rng.uniform(-0.15, 0.15, (E, N, 2)), rng.uniform(0.51, 0.62, (E, N, 1))], -1).astype(np.float32)
+    pos[:, 0] = [0, 0, 0.5125]                                            # agent 0 rests on the ground in every env
+    pos[:, 1, :2] = [[0.05 + 0.02 * e, 0.0] for e in range(E)]            # agent 1 next to it
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, START_POS=torch.from_numpy(pos))
+    env.reset(ori=torch.zeros(E, N, 3))
+    singles = []
+    for e in range(E):
+        one = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, START_POS=torch.from_numpy(pos[e]))
+        one.reset(ori=torch.zeros(N, 3))
+        singles.append(one)
+    for i in (0, 1, 3):
+        q = env.get_agents()[i]
+        for other in (None, 1 if i != 1 else 0):
+            c = q.get_contact_points(other=other)
+            assert c["object"].shape == (E, N) and c["pos"].shape == (E, N, 3) and c["distance"].shape == (E, N) and c["count"].shape == (E,)
+            for e in range(E):
+                s = singles[e].get_agents()[i].get_contact_points(other=None if other is None else singles[e].get_agents()[other])
+                n = int(c["count"][e])
+                assert n == len(s["object"])
+                want = [o.uid for o in s["object"]]
+                assert c["object"][e, :n].tolist() == want and bool((c["object"][e, n:] == -1).all())
+                if n:
+                    np.testing.assert_allclose(c["pos"][e, :n].cpu().numpy(), s["pos"].cpu().numpy(), atol=1e-6)
+                    np.testing.assert_allclose(c["distance"][e, :n].cpu().numpy(), s["distance"].cpu().numpy(), atol=1e-6)
+        for radius in (0.1, 0.3):
+            g = q.get_closest_objects(radius)
+            for e in range(E):
+                want = [o.uid for o in singles[e].get_agents()[i].get_closest_objects(radius)]
+                n = int(g["count"][e])
+                assert g["object"][e, :n].tolist() == want and bool((g["object"][e, n:] == -1).all())
+    assert int(env.get_agents()[0].get_contact_points()["count"].min()) >= 1     # the ground, at least

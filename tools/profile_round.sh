@@ -9,11 +9,11 @@ out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 export MRS_BENCH_PREWARM_S=0   # profile the measured swarm only
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --steps 1000 --warmup 100 --no-cpu-baseline --no-dense-a > "$out/bench.json" 2> "$out/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --steps 1000 --warmup 100 --no-cpu-baseline --no-dense-a --no-double-buffer > "$out/bench.json" 2> "$out/stats.err"
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 300 --warmup 100 --no-cpu-baseline --no-dense-a > /dev/null 2> "$out/$c.err"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 300 --warmup 100 --no-cpu-baseline --no-dense-a --no-double-buffer > /dev/null 2> "$out/$c.err"
   echo "$c done"
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d "$out/SQ" -o run -- python3 "$root/bench.py" --steps 300 --warmup 100 --no-cpu-baseline --no-dense-a > /dev/null 2> "$out/SQ.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d "$out/SQ" -o run -- python3 "$root/bench.py" --steps 300 --warmup 100 --no-cpu-baseline --no-dense-a --no-double-buffer > /dev/null 2> "$out/SQ.err"
 echo "SQ done"
