@@ -254,7 +254,7 @@ struct Observed {
 };
 
 template <bool WANT_EULER, bool WANT_MAT>
-MRS_DEV void observe(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, double *ang = nullptr)
+MRS_DEV void observe(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o)
 {
     o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
     o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
@@ -266,7 +266,6 @@ MRS_DEV void observe(const double p[3], const double q[4], const double v[3], co
             double r, pt, y;
             matrix_to_euler(R, r, pt, y);
             o.roll = (float)r; o.pitch = (float)pt; o.yaw = (float)y;
-            if (ang) { ang[0] = r; ang[1] = pt; ang[2] = y; } // float64 angles for the next step's controller (observe_ctrl)
         }
         if (WANT_MAT) {
             o.r00 = (float)R.m00; o.r01 = (float)R.m01; o.r02 = (float)R.m02;
@@ -287,10 +286,8 @@ MRS_DEV void rot_small(double s, double c, double d, double &so, double &co)
     so = __builtin_fma(c, d, s) - s * t;
     co = __builtin_fma(-s, d, c) - c * t;
 }
-// `carried`: the three float64 angles of exactly this float32 quaternion, evaluated by the previous step's observation
-// slice (observe<true, .>) -- wave-uniform pointer or null.
 // `rounded` (MrsParams.round_euler_readback, uniform over the launch): false takes Re = R, see below.
-MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re, bool rounded, const double *carried = nullptr)
+MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3], const double w[3], Observed &o, M3 &Re, bool rounded)
 {
     o.px = (float)p[0]; o.py = (float)p[1]; o.pz = (float)p[2];
     o.vx = (float)v[0]; o.vy = (float)v[1]; o.vz = (float)v[2];
@@ -313,8 +310,7 @@ MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3
     }
     const double h = sqrt64(R.m21 * R.m21 + R.m22 * R.m22);
     double r, pt, y;
-    if (carried) { r = carried[0]; pt = carried[1]; y = carried[2]; }
-    else { r = fast_atan2(R.m21, R.m22); pt = fast_atan2(-R.m20, h); y = fast_atan2(R.m10, R.m00); }
+    r = fast_atan2(R.m21, R.m22); pt = fast_atan2(-R.m20, h); y = fast_atan2(R.m10, R.m00);
     o.roll = (float)r; o.pitch = (float)pt; o.yaw = (float)y;
     o.r00 = (float)R.m00; o.r01 = (float)R.m01; o.r02 = (float)R.m02;
     o.r10 = (float)R.m10; o.r11 = (float)R.m11; o.r12 = (float)R.m12;

@@ -63,23 +63,11 @@ struct StepArgs {
     int *contact_count, *contact_count_next, *contact_list; // library workspace (MrsHandle)
     double *contact_state;                                  // [13][T] parked states, indexed by list slot
     DownwashConst dc;   // host-computed once per call
-    // Euler angles carried from the previous step's observation slice to this step's attitude controller (MRS_EUL_CARRY)
-    float4 *eul_key;    // [T] the float32 quaternion the angles were evaluated from (Object.py:92-93)
-    double *eul_ang;    // [3][T] float64 roll, pitch, yaw (Object.py:97 before the float32 truncation)
     MrsParams P;
 };
 
-// Velocity planes: float64 like Bullet's state, or (MRS_VEL_F32) float32 -- what every consumer of the state reads
-// back anyway (Object.py:78-83); the step still integrates them in float64 registers.
-#ifndef MRS_VEL_F32
-#define MRS_VEL_F32 0
-#endif
-#if MRS_VEL_F32
-typedef float vel_t;
-#else
-typedef double vel_t;
-#endif
-#define VELP(ptr) (reinterpret_cast<vel_t *>(ptr))
+typedef double vel_t; // velocity planes: float64 like Bullet's state (float32 planes were measured: -0.3 us, not worth the parity loss)
+#define VELP(ptr) (ptr)
 __device__ __forceinline__ void load_state(const MrsBuffers &b, size_t a, size_t T, double p[3], double q[4], double v[3], double w[3])
 {
     p[0] = b.pos[a]; p[1] = b.pos[T + a]; p[2] = b.pos[2 * T + a];
@@ -95,18 +83,11 @@ __device__ __forceinline__ void store_state(const MrsBuffers &b, size_t a, size_
     VELP(b.angvel)[a] = (vel_t)w[0]; VELP(b.angvel)[T + a] = (vel_t)w[1]; VELP(b.angvel)[2 * T + a] = (vel_t)w[2];
 }
 
-// Stores that leave the XCD's L2 at once (global_store ... sc1: agent-scope, write-through) instead of sitting there dirty
-// until the end-of-kernel release writes them back.  MRS_WT bits (A/B switch): 1 state planes, 2 observation + adjacency,
-// 4 controller memory.
-#ifndef MRS_WT
-#define MRS_WT 0
-#endif
+// (Round 3 experiment, removed: global_store ... sc1, agent-scope write-through, so that the step's stores do not sit dirty in
+// the XCD's L2 until the end-of-kernel release.  State planes: -0.3 ... +0.2 us, inside the noise; the 8-byte observation /
+// adjacency stores: +2 us, each becomes a fabric write; controller memory: +-0.)
 template <int BIT, class T>
-__device__ __forceinline__ void st(T *ptr, T v)
-{
-    if (MRS_WT & BIT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *ptr = v;
-}
+__device__ __forceinline__ void st(T *ptr, T v) { *ptr = v; }
 
 // Workgroup-relative addressing.  Agent a = wg_base + tid for every live lane of k_step / k_observe_adj, so a
 // plane access is (uniform pointer, SGPR pair) + (small 32-bit per-lane offset): the saddr form of global_load /
@@ -144,32 +125,11 @@ __device__ __forceinline__ void store_state(const WgBuffers &b, unsigned t, size
     st<1>(b.angvel + t, (vel_t)w[0]); st<1>(b.angvel + T + t, (vel_t)w[1]); st<1>(b.angvel + 2 * T + t, (vel_t)w[2]);
 }
 
-// The attitude controller of step t+1 reads the Euler angles of the state step t left behind (Quadcopter.py:54-61 ->
-// Object.get_ori) -- the angles step t's observation slice has just evaluated for the caller's state_fn.  With
-// MRS_EUL_CARRY the slice also leaves them, in float64 and keyed by the float32 quaternion they belong to, in a library
-// workspace; the next step uses them iff every lane of the wave finds its key equal to its current float32 quaternion
-// (anything that rewrites the state in between -- set_state, spawn, reset -- simply fails the comparison) and otherwise
-// evaluates sqrt + 3 atan2 (~130 float64 instructions) itself.  Same values either way: the angles are a function of
-// the float32 quaternion alone.
-// Off by default: it pays only when the caller's observation contains the Euler angles.  With the bench's
-// state_fn = cat(pos, vel) nothing is carried and the 40 B key + angle loads per agent are pure cost (measured, same box:
-// 28.2 us per step against 27.5; tools/micro/skeleton.hip: the step's loads and stores alone take 15 us per launch, so
-// bytes are not free).
-#ifndef MRS_EUL_CARRY
-#define MRS_EUL_CARRY 0
-#endif
 // newest observation slice, (E,N,D) row-major: Environment.get_X of a concatenating state_fn
-__device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3],
-                                          float4 *eul_key = nullptr, double *eul_ang = nullptr, size_t T = 0)
+__device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
 {
     // state_fn = cat(pos, vel) (README.md:28-29, the bench's): the 24-byte row as three 8-byte stores instead of six
-    if (n_obs == 2 && code == (MRS_OBS_POS | (MRS_OBS_VEL << 4)) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0 && !eul_key) {
-        if (MRS_WT & 2) {
-            unsigned long long *o8 = reinterpret_cast<unsigned long long *>(o);
-            auto pk = [](float a, float b) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32); };
-            st<2>(o8, pk((float)p[0], (float)p[1])); st<2>(o8 + 1, pk((float)p[2], (float)v[0])); st<2>(o8 + 2, pk((float)v[1], (float)v[2]));
-            return;
-        }
+    if (n_obs == 2 && code == (MRS_OBS_POS | (MRS_OBS_VEL << 4)) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
         float2 *o2 = reinterpret_cast<float2 *>(o);
         o2[0] = make_float2((float)p[0], (float)p[1]); o2[1] = make_float2((float)p[2], (float)v[0]); o2[2] = make_float2((float)v[1], (float)v[2]);
         return;
@@ -177,14 +137,8 @@ __device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, co
     bool want_euler = false;
     for (int f = 0; f < n_obs; ++f) want_euler |= (((code >> (4 * f)) & 15u) == MRS_OBS_EULER);
     Observed ob;
-    if (want_euler) {
-        double ang[3];
-        observe<true, false>(p, q, v, w, ob, ang);
-        if (eul_key) {
-            *eul_key = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-            eul_ang[0] = ang[0]; eul_ang[T] = ang[1]; eul_ang[2 * T] = ang[2];
-        }
-    } else observe<false, false>(p, q, v, w, ob);
+    if (want_euler) observe<true, false>(p, q, v, w, ob);
+    else observe<false, false>(p, q, v, w, ob);
     int off = 0;
     for (int f = 0; f < n_obs; ++f) {
         switch ((code >> (4 * f)) & 15u) {
@@ -197,10 +151,9 @@ __device__ __forceinline__ void write_obs(unsigned code, int n_obs, float *o, co
         }
     }
 }
-__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3],
-                                          float4 *eul_key = nullptr, double *eul_ang = nullptr)
+__device__ __forceinline__ void write_obs(const StepArgs &A, float *o, const double p[3], const double q[4], const double v[3], const double w[3])
 {
-    write_obs(A.obs_code, A.n_obs, o, p, q, v, w, eul_key, eul_ang, (size_t)A.T);
+    write_obs(A.obs_code, A.n_obs, o, p, q, v, w);
 }
 
 // two float32 in an aligned register pair: the operand form of the packed instructions (v_pk_add/mul/fma_f32: two IEEE
@@ -453,11 +406,11 @@ __device__ __forceinline__ void adj64_flag(const StepArgs &A, const float *t, fl
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 // Also (A.pair_flag): notes per env whether any pair of it is within quad-quad contact range of these positions -- the
 // squared distances are formed here anyway -- for the step that starts from them.  row may be null (flag only).
-template <int BLOCK, int NFIX = 0>
+template <int BLOCK>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
                                                 uint64_t *row, float4 mine, int e)
 {
-    const bool n64 = (NFIX == 64 || A.N == 64);
+    const bool n64 = A.N == 64;
     const bool want_hit = A.pair_flag != nullptr;
     int *const hit_flag = reinterpret_cast<int *>(lds_tile) + 3 * BLOCK; // generic N: one word per env slot, behind the three arrays
     if (!n64 && want_hit && tid < A.epb) hit_flag[tid] = 0;
@@ -577,29 +530,6 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 // pose/outputs 0) keeps them abreast: 34.3 -> 31.8 us per step.  The contact solve, the one serial stretch that
 // three waves of its workgroup wait for, runs at 3.  Round 2: all four levels in use (pair loop 3, controller 2,
 // forces 1, outputs 0): 29.2 -> 28.7 us; equal priorities cost +2.5 us, leaders-first +2.8 us (tools/abl_run.sh).
-// MRS_AB_PRIO: two priority classes of WORKGROUPS (by the workgroup's slot on its CU, HW_ID.tg_id).  All waves of the
-// bench swarm are resident in one round and, at equal priorities, march through load -> forces -> contact -> outputs
-// in lock-step: during the contact hand-off every SIMD is down to its solver waves.  Class A runs ahead of class B,
-// so that A's contact solve overlaps B's forces phase and B's overlaps A's outputs.
-#ifndef MRS_AB_PRIO
-#define MRS_AB_PRIO 0
-#endif
-#ifndef MRS_NFIX64
-#define MRS_NFIX64 0
-#endif
-#ifndef MRS_PA_DW
-#define MRS_PA_DW 3
-#define MRS_PA_CTRL 3
-#define MRS_PA_TAIL 2
-#define MRS_PB_DW 1
-#define MRS_PB_CTRL 1
-#define MRS_PB_TAIL 0
-#endif
-#if MRS_AB_PRIO
-#define SETPRIO(both, a, b) do { if (cls_a) __builtin_amdgcn_s_setprio(a); else __builtin_amdgcn_s_setprio(b); } while (0)
-#else
-#define SETPRIO(both, a, b) __builtin_amdgcn_s_setprio(both)
-#endif
 #ifndef MRS_P_DW1
 #define MRS_P_DW1 3
 #define MRS_P_DW2 3
@@ -625,11 +555,10 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 // three-launch form pays it three times (measured: tools/micro/launch_floor.hip).
 // FUSED = false: velocities only; grounded bodies are queued for k_contact, observation/adjacency follow in
 // k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
-// NFIX = 64: the instantiation for N_AGENTS = 64 (one env per wave; the generic-N branches fold away), 0: any N.
-template <int ACT, int BLOCK, bool FUSED, int NFIX = 0>
+template <int ACT, int BLOCK, bool FUSED>
 __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : (FUSED ? 4 : 1))) void k_step(const StepArgs A)
 {
-    const int AN = NFIX ? NFIX : A.N, AEPB = NFIX ? BLOCK / (NFIX ? NFIX : 1) : A.epb, AW = NFIX ? (NFIX + 63) / 64 : A.W;
+    const int AN = A.N, AEPB = A.epb, AW = A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
@@ -687,15 +616,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #endif
     }
     TL(9); // kernel arguments arrived, first loads issued
-    // angles carried from the previous step's observation slice (see MRS_EUL_CARRY)
-    constexpr bool EUL = MRS_EUL_CARRY && FUSED && (ACT >= MRS_ACT_TARGET_ACCEL);
-    float4 ekey = make_float4(0.f, 0.f, 0.f, 0.f);
-    double eang[3] = {0, 0, 0};
-    if (EUL && A.eul_key != nullptr && live) {
-        ekey = (A.eul_key + wb_base)[la];
-        const double *ea = A.eul_ang + wb_base;
-        eang[0] = ea[la]; eang[1] = (ea + T)[la]; eang[2] = (ea + 2 * T)[la];
-    }
 #if MRS_DEFER_LOADS
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -752,15 +672,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool doit = live && !masked && !env_nan;
     if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
-#if MRS_AB_PRIO
-    bool cls_a = false;
-    if (FUSED) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        cls_a = (MRS_AB_PRIO == 1 ? (hw >> 16) : hw) & 1u; // 1: tg_id[19:16], 2: wave slot id[3:0]
-    }
-#endif
-    if (FUSED) SETPRIO(MRS_P_DW1, MRS_PA_DW, MRS_PB_DW);
+    if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_DW1);
     int my_slot = -1;
     bool parked = false;
 #if !MRS_EXACT_F32
@@ -875,7 +787,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
         }
         TL(1); // pair loop
-        if (FUSED) SETPRIO(MRS_P_CTRL, MRS_PA_CTRL, MRS_PB_CTRL);
+        if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_CTRL);
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
             double rpm[4];
@@ -915,13 +827,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             Observed ob;
             M3 R; // from_euler(float32 euler read-back): only the PID modes use it
             if (NEEDS_PID) {
-                bool have_eul = false;
-                if (EUL && A.eul_key != nullptr) {
-                    const bool stale = live && !(ekey.x == (float)q[0] && ekey.y == (float)q[1] && ekey.z == (float)q[2] && ekey.w == (float)q[3]);
-                    have_eul = __builtin_amdgcn_ballot_w64(stale) == 0;
-                }
-                const bool rounded = A.P.round_euler_readback != 0;
-                if (have_eul) observe_ctrl(p, q, v, w, ob, R, rounded, eang); else observe_ctrl(p, q, v, w, ob, R, rounded);
+                observe_ctrl(p, q, v, w, ob, R, A.P.round_euler_readback != 0);
             } else observe<true, true>(p, q, v, w, ob);
             TL(21); // read-back + rotation matrices
             if (NEEDS_PID) {
@@ -1145,7 +1051,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 sp[7 * BLOCK + b] += (double)dv.x; sp[8 * BLOCK + b] += (double)dv.y; sp[9 * BLOCK + b] += (double)dv.z;
                 sp[10 * BLOCK + b] += (double)dw.x; sp[11 * BLOCK + b] += (double)dw.y; sp[12 * BLOCK + b] += (double)dw.z;
             }
-            SETPRIO(0, MRS_PA_TAIL, MRS_PB_TAIL);
+            __builtin_amdgcn_s_setprio(0);
             TL(5); // own share of the contact solve
             __syncthreads();
         }
@@ -1160,14 +1066,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 integrate_pose(A.P, p, q, v, w);
                 if (KO_KEEP(1)) store_state(wb, la, T, p, q, v, w);
             }
-            if (A.b.obs && live && A.n_obs > 0 && KO_KEEP(2))
-                write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w, MRS_EUL_CARRY && A.eul_key ? A.eul_key + wb_base + la : nullptr, MRS_EUL_CARRY && A.eul_key ? A.eul_ang + wb_base + la : nullptr);
+            if (A.b.obs && live && A.n_obs > 0 && KO_KEEP(2)) {
+                // (Round 3 experiment, removed: the wave's 64 observation rows of 24 bytes staged through the free position tile and
+                // stored as 16-byte whole-line pieces instead of three 8-byte stores at a 24-byte stride: 22.4 against 22.4 us.)
+                write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
+            }
         };
         // (Round 3 experiment, removed: the lanes that are not listed for the solve -- 19 out of 20 -- finishing their step
         // between the two barriers, under the solver wave's serial chain, and the listed ones behind it.  25.9 against 23.4 us
         // per step: two exec-masked passes over the 13 state stores write partial cache lines instead of whole ones.)
         TL(6); // barrier 2
-        SETPRIO(MRS_P_TAIL, MRS_PA_TAIL, MRS_PB_TAIL); // last phase, lowest priority: see MRS_P_* above
+        __builtin_amdgcn_s_setprio(MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
         reload();
         // (the mirror image of MRS_LATE_LOADS -- the 13 state stores spread over the passes of the adjacency pair loop
         // instead of one burst ahead of it -- was measured: no gain, 27.0 against 27.0 us per step)
@@ -1188,7 +1097,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int e2 = blockIdx.x * AEPB + (n64 ? (t2 >> 6) : el);
-            adjacency_phase<BLOCK, NFIX>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
+            adjacency_phase<BLOCK>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
                                          A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
                                          make_float4(fpx, fpy, fpz, 0.f), e2);
         }
@@ -1553,8 +1462,6 @@ struct MrsHandle {
     int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
     unsigned long long *pair_rows; // device workspace [T][W]: the candidates per agent (StepArgs.pair_rows)
     bool big_lds[MRS_ACT_TARGET_ORI + 1]; // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device, per ACTION_TYPE
-    float4 *eul_key;    // device workspace, fused step: Euler angles carried from a step's observation slice to the next
-    double *eul_ang;    //   step's attitude controller (see MRS_EUL_CARRY): float32 quaternion key [T], float64 angles [3][T]
 };
 
 static thread_local char g_err[256] = "";
@@ -1709,25 +1616,16 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         if (e == hipSuccess) e = hipDeviceSynchronize(); // null-stream memset: ordered before any caller stream's first step
         if (e == hipSuccess) e = hipMalloc((void **)&h->cs, 13 * (size_t)n_envs * n_agents * sizeof(double));
     }
-    h->eul_key = nullptr; h->eul_ang = nullptr; h->pair_flag = nullptr; h->pair_rows = nullptr;
+    h->pair_flag = nullptr; h->pair_rows = nullptr;
     if (e == hipSuccess) {
         e = hipMalloc((void **)&h->pair_flag, (size_t)n_envs * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->pair_rows, (size_t)n_envs * n_agents * (size_t)((n_agents + 63) / 64) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->pair_flag, 1, (size_t)n_envs * sizeof(int)); // nothing known yet: every env looks
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    if (e == hipSuccess && h->fused && MRS_EUL_CARRY) {
-        const size_t T = (size_t)n_envs * n_agents;
-        e = hipMalloc((void **)&h->eul_key, T * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->eul_ang, 3 * T * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(h->eul_key, 0xFF, T * sizeof(float4)); // NaN keys: nothing carried yet
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
     if (e != hipSuccess) {
         if (h->ws) (void)hipFree(h->ws);
         if (h->cs) (void)hipFree(h->cs);
-        if (h->eul_key) (void)hipFree(h->eul_key);
-        if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->pair_flag) (void)hipFree(h->pair_flag);
         if (h->pair_rows) (void)hipFree(h->pair_rows);
         (void)hipSetDevice(cur);
@@ -1742,12 +1640,10 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
-    if (h->ws || h->cs || h->eul_key || h->eul_ang || h->pair_flag || h->pair_rows) {
+    if (h->ws || h->cs || h->pair_flag || h->pair_rows) {
         DeviceGuard dg(h->device);
         if (h->pair_flag) (void)hipFree(h->pair_flag);
         if (h->pair_rows) (void)hipFree(h->pair_rows);
-        if (h->eul_key) (void)hipFree(h->eul_key);
-        if (h->eul_ang) (void)hipFree(h->eul_ang);
         if (h->ws) (void)hipFree(h->ws);
         if (h->cs) (void)hipFree(h->cs);
     }
@@ -1780,7 +1676,6 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
         c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
         c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
         c.lg_alpha = (float)std::log2((double)c.c_alpha);
-        A.eul_key = h->eul_key; A.eul_ang = h->eul_ang;
     }
     A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
     A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf); A.rc.inv_dt = 1.0 / h->P.dt;
@@ -1803,10 +1698,6 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
     const int grid = (h->E + h->epb - 1) / h->epb;
     const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 258 * sizeof(int);
     // fused: + compacted lane list + 13 float64 state planes + per-wave counts (36 888 B; 4 workgroups per CU fit the 160 KB LDS)
-#if MRS_NFIX64
-    if (fused && h->N == 64) hipLaunchKernelGGL((k_step<ACT, 256, true, 64>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
-    else
-#endif
     if (fused && h->sblock != 256) { // N = 64 with fewer envs (waves) per workgroup: same kernel, smaller hand-off group
         StepArgs B = A;
         B.epb = std::min(h->sblock / h->N, 256); // whole envs per workgroup (the NaN-flag array holds 256)

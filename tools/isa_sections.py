@@ -2,18 +2,18 @@
 
     python tools/isa_sections.py [extra -D flags]
 
-Compiles mrs_kernels.hip with -DMRS_MARKS -DMRS_NFIX64=1 (phase boundaries as '; MRS_MARK k' comments, generic-N
-branches folded away) to assembly and histograms the vector instructions between consecutive marks, in layout order.
+Compiles mrs_kernels.hip with -DMRS_MARKS (phase boundaries as '; MRS_MARK k' comments; the generic-N branches of the
+run-time-N kernel are in the listing too, so the static counts are upper bounds of what an N = 64 wave executes) to assembly and histograms the vector instructions between consecutive marks, in layout order.
 The contact-sweep loop body is counted once (it runs up to solver_iters times)."""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flags = sys.argv[1:]
 out = "/tmp/isa_sections.s"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DMRS_MARKS", "-DMRS_NFIX64=1",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DMRS_MARKS",
                        "-S", "--cuda-device-only", os.path.join(ROOT, "mrs-gym_amd/csrc/mrs_kernels.hip"), "-o", out] + flags,
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()
-m = re.search(r"^_Z6k_stepILi4ELi256ELb1ELi64EEv8StepArgs:.*?s_endpgm", txt, re.S | re.M)
+m = re.search(r"^_Z6k_stepILi4ELi256ELb1EEv8StepArgs:.*?s_endpgm", txt, re.S | re.M)
 body = m.group(0).split("\n")
 names = {"0": "downwash pairs", "1": "vel/pos control", "20": "read-back + R", "21": "attitude ctrl", "2": "forces/gnd/drag", "22": "integrate vel",
          "3": "stash+ballot", "4": "contact solve", "5": "(after solve)", "6": "pose+store", "7": "obs+adjacency", "8": "end"}
