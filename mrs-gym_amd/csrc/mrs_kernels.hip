@@ -682,8 +682,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // yet used state stash: R distances per workgroup barrier, double-buffered, received terms added in distance
     // order (deterministic).  Half the transcendental work of the all-pairs loop (N = 256 x 1024 envs: 83.4 -> 77.2 us).
     // Every thread runs the loop: the barriers are workgroup-wide and the trip count depends on N only.
+    // (Round 3 experiment, removed: the handed-over terms ADDED into one LDS word per receiving agent -- 64-bit fixed point, so
+    // that the sum does not depend on the order of arrival -- instead of laid out per ring distance and summed after a
+    // barrier per eight distances: N = 256 x 1024 envs 66.9 against 61.8 us per step, N = 128: 40.8 against 38.1.)
     constexpr int RING_R = 8;
-    if (ring) {
+    if (ring && KO_KEEP(8)) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
         const float *tx = ring_x + i, *ty = ring_x + 2 * AN + i, *tz = ring_x + 4 * AN + i; // neighbour i + k at offset k, no wrap
         const DownwashRegs dr = downwash_regs(A.dc);
