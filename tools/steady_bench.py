@@ -34,9 +34,13 @@ acts = ActionStream(ATYPE, E, N, pos, seed=1000)
 table = [torch.from_numpy(acts(50 * k)).cuda() for k in range((ROLLIN + K * REPS) // 50 + 2)]
 obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
 at = ACT[ATYPE]
+if os.environ.get("NOADJ"):          # RETURN_A = False (BASELINE config 2): no adjacency rows
+    adj = None
+ADJ = adj.data_ptr() if adj is not None else 0
+CR = 5.0 if adj is not None else float("nan")
 t = 0
 for _ in range(ROLLIN):
-    sh.step_ptr(table[t // 50], at, obs.data_ptr(), adj.data_ptr(), 5.0); t += 1
+    sh.step_ptr(table[t // 50], at, obs.data_ptr(), ADJ, CR); t += 1
 torch.cuda.synchronize()
 if os.environ.get("KO"):            # a -DMRS_KO=-1 build: parts of the step switched off for the timed steps only (tools/abl_run.sh "name:KO=3")
     os.environ["MRS_KO"] = os.environ["KO"]
@@ -45,7 +49,7 @@ for r in range(REPS):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(K):
-        sh.step_ptr(table[t // 50], at, obs.data_ptr(), adj.data_ptr(), 5.0); t += 1
+        sh.step_ptr(table[t // 50], at, obs.data_ptr(), ADJ, CR); t += 1
     e1.record(); torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / K * 1e3)
 grounded = float((sh.pos[2] < 0.6).float().mean())
