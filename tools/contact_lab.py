@@ -665,3 +665,30 @@ def pgs12_warm(P, iters, l0n, l0t, have, tol=1e-7, stag=0.5):
 
 if len(sys.argv) > 1 and sys.argv[1] == "warm":
     warm_study()
+
+
+def table():
+    """What DESIGN.md section 5 quotes (profiles/r03_contact_lab.txt)."""
+    d = np.load(OUT); P = Prob(d)
+    print("# tools/contact_lab.py table: %d contact problems of the bench workload on the CPU oracle (24 envs x 64 agents, steps 700-800)" % P.M)
+    print("active rim points per problem: %s" % dict(enumerate(np.bincount(P.act.sum(1), minlength=5).tolist())))
+    d = d[P.act.any(1)]; P = Prob(d)
+    tilt = np.maximum(np.abs(P.R[:, 2, 0]), np.abs(P.R[:, 2, 1])); wn = np.abs(P.w).max(1); vxy = np.abs(P.v[:, :2]).max(1)
+    for eps in (1e-9, 1e-6, 1e-5):
+        rest = P.act.all(1) & (tilt < eps) & (wn < eps) & (vxy < eps)
+        print("at rest (|R20|, |R21|, |w|, |v_xy| < %g, four active points): %.1f %% of the problems" % (eps, 100.0 * rest.mean()))
+    ref = pgs12(P, 400, tol=0, stag=2.0)[:2]
+    print("error of the velocity change against the converged solution (400 sweeps), max(|dv|, 0.06 |dw|) in m/s, and sweeps run:")
+    for cap in (2, 4, 6, 8, 10):
+        dv, dw, used, _, _ = pgs12(P, cap)
+        e = np.maximum(np.abs(dv - ref[0]).max(1), 0.06 * np.abs(dw - ref[1]).max(1))
+        print("  at most %2d sweeps: mean sweeps %.2f | error median %.1e  90 %% %.1e  99 %% %.1e  99.9 %% %.1e  max %.1e" % (
+            cap, used.mean(), np.median(e), np.quantile(e, .9), np.quantile(e, .99), np.quantile(e, .999), e.max()))
+    dv, dw, used, _, _ = pgs12(P, 10)
+    rest = P.act.all(1) & (tilt < 1e-6) & (wn < 1e-6) & (vxy < 1e-6)
+    print("sweeps wanted under the cap of 10 (convergence or stagnation): all %s; not at rest %s" % (
+        dict((i, int(c)) for i, c in enumerate(np.bincount(used)) if c), dict((i, int(c)) for i, c in enumerate(np.bincount(used[~rest])) if c)))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "table":
+    table()
