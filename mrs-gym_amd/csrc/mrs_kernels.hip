@@ -279,10 +279,23 @@ __device__ __forceinline__ void tile64_write(float4 *lds_tile, int el, int i, fl
     t[i] = t[64 + i] = x; t[128 + i] = t[192 + i] = y; t[256 + i] = t[320 + i] = z;
 }
 // the differences to neighbours k and k+1 of the lane whose tile pointer (already offset by the lane) is t
-__device__ __forceinline__ void tile64_rel2(const float *t, int k, f2 mx, f2 my, f2 mz, f2 &rx, f2 &ry, f2 &rz)
+// The z array sits 256 dwords behind x, one more than ds_read2_b32's offset field reaches: "t[256 + k]" costs an address
+// addition per pass.  tz = the LDS address of t + 256 in a register of its own (kept an LDS pointer: laundering a generic
+// pointer through asm would turn the reads into flat loads -- measured, +4 us; as it stands -46 instructions, -0.1 ... -0.2 us).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ lds_cfloat *tile64_z(const float *t)
 {
-    rx = pk_sub(f2{t[k], t[k + 1]}, mx); ry = pk_sub(f2{t[128 + k], t[128 + k + 1]}, my); rz = pk_sub(f2{t[256 + k], t[256 + k + 1]}, mz);
+    unsigned off = (unsigned)(uintptr_t)(lds_cfloat *)(t + 256);
+    asm volatile("" : "+v"(off));
+    return (lds_cfloat *)(uintptr_t)off;
 }
+#define TILE64_Z(t) lds_cfloat *const tz = tile64_z(t)
+template <class PZ>
+__device__ __forceinline__ void tile64_rel2z(const float *t, PZ tz, int k, f2 mx, f2 my, f2 mz, f2 &rx, f2 &ry, f2 &rz)
+{
+    rx = pk_sub(f2{t[k], t[k + 1]}, mx); ry = pk_sub(f2{t[128 + k], t[128 + k + 1]}, my); rz = pk_sub(f2{tz[k], tz[k + 1]}, mz);
+}
+#define tile64_rel2(t, k, mx, my, mz, rx, ry, rz) tile64_rel2z(t, tz, k, mx, my, mz, rx, ry, rz)
 
 // StepArgs.pair_flag[e], N = 64: exactly ONE pair of the env is within contact range, agents (flag & 63) and (flag >> 8 & 63).
 // By far the common case among the flagged envs, and the step kernel's duration is that of its slowest wave: a wave that scans
@@ -317,6 +330,7 @@ __device__ __forceinline__ void adj64_pass(const float *t, float mex, float mey,
     asm volatile("" : "+v"(thr));
     dmin = __builtin_huge_valf();
     const f2 mx = splat(mex), my = splat(mey), mz = splat(mez);
+    TILE64_Z(t);
     if (rows) {
         auto verdict = [&](int k, float d2) {
             const uint32_t bit = d2 <= thr ? (1u << k) : 0u;
@@ -461,6 +475,7 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 {
     const DownwashRegs dr = downwash_regs(dc);
     const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
+    TILE64_Z(t);
     // Magnitudes are summed and the sign is applied once at the end (-(a + b) == (-a) + (-b) bit for bit).  The terms a lane
     // keeps: float32 partial sums of two per pass, flushed to float64 every four passes.  The terms for the lower quadcopter
     // of a pair travel to it in `trav` (see wave_ror1), k descending; a lane receives 31 of them as one float32 sum.
