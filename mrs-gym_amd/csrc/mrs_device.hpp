@@ -85,6 +85,14 @@ MRS_DEV double rcp64(double x)
     r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
     return r;
 }
+// 1 / x to ~1e-14 relative from the float32 reciprocal unit (v_rcp_f32, 1 ulp = 6e-8) and one Newton step: for factors that
+// multiply a small term (the ground effect is ~1e-4 of a rotor's thrust), where the ~1e-16 of rcp64 buys nothing and
+// v_rcp_f64 costs twice the issue slots of the float32 unit.  x positive, normal, inside the float32 range.
+MRS_DEV double rcp64_coarse(double x)
+{
+    const double r = (double)__builtin_amdgcn_rcpf((float)x);
+    return r * __builtin_fma(-x, r, 2.0);
+}
 MRS_DEV double rsqrt64(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
@@ -333,7 +341,19 @@ MRS_DEV void observe_ctrl(const double p[3], const double q[4], const double v[3
 // otherwise still cost every lane its ~12-instruction division sequence).
 struct Recips {
     double inv_mass, inv_i0, inv_i1, inv_i2, inv_4kf, inv_dt; // host-computed: a float64 division is ~14 VALU per lane
+    // float32 division by the controller's DT (QuadControl.py:62) as multiply + two fused multiply-adds, bit for bit the
+    // correctly rounded quotient: r = RN(1 / dt32), q0 = RN(x r), q = RN(q0 + r (x - dt32 q0)) (Markstein; holds for every
+    // divisor whose significand is not all ones -- ctrl_div_fast says so -- and checked over all 3.8e9 finite float32 x for
+    // the default 0.01f).  The compiler's division is ten instructions, three times per agent-step.
+    float inv_ctrl_dt32;
+    int ctrl_div_fast;
 };
+MRS_DEV float div_ctrl_dt(float x, float dt32, const Recips &K)
+{
+    if (!K.ctrl_div_fast) return f32div(x, dt32);
+    const float q0 = f32mul(x, K.inv_ctrl_dt32);
+    return __builtin_fmaf(__builtin_fmaf(-dt32, q0, x), K.inv_ctrl_dt32, q0);
+}
 
 // Controller memory of one quadcopter, in registers for the duration of a step.
 struct Pid {
@@ -359,8 +379,8 @@ MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const
     const double a01 = Rt.m00 * R.m01 + Rt.m10 * R.m11 + Rt.m20 * R.m21;
     const double ex = a21 - a12, ey = a02 - a20, ez = a10 - a01;
     const double dt = P.ctrl_dt;
-    s.iox = clampd(clampd(s.iox - ex * dt, -1500., 1500.), -1., 1.); // :108-110
-    s.ioy = clampd(clampd(s.ioy - ey * dt, -1500., 1500.), -1., 1.);
+    s.iox = clampd(s.iox - ex * dt, -1., 1.); // :108-110: clip to +-1500, then x and y to +-1 -- the second contains the first
+    s.ioy = clampd(s.ioy - ey * dt, -1., 1.);
     s.ioz = clampd(s.ioz - ez * dt, -1500., 1500.);
     // :112-115  P=(7e4,7e4,6e4) I=(0,0,500) D=(2e4,2e4,1.2e4), angvel_e = 0 - angvel
     const double tx = clampd(-(70000. * ex) + 0. * s.iox + 20000. * (0.0 - (double)o.wx), -3200., 3200.);
@@ -405,16 +425,16 @@ MRS_DEV void accel_control(const MrsParams &P, const Recips &K, Pid &s, V3 ta_in
 }
 
 // QuadControl.vel_control (QuadControl.py:51-70): vel_e and the derivative numerator are float32 arithmetic
-MRS_DEV V3 vel_control_accel(const MrsParams &P, Pid &s, const Observed &o, float tvx, float tvy, float tvz)
+MRS_DEV V3 vel_control_accel(const MrsParams &P, const Recips &K, Pid &s, const Observed &o, float tvx, float tvy, float tvz)
 {
     const float dt32 = (float)P.ctrl_dt;
     const float ex = f32sub(tvx, o.vx), ey = f32sub(tvy, o.vy), ez = f32sub(tvz, o.vz); // :54
     if (isnan(s.lvx)) { s.lvx = ex; s.lvy = ey; s.lvz = ez; s.dvx = s.dvy = s.dvz = 0.; }       // :55-57
     if (isnan(s.ltx)) { s.ltx = tvx; s.lty = tvy; s.ltz = tvz; }                                // :58-59
     // :62 d = (((e - e_last) - (tv - tv_last)) / DT) * 0.5 + d * 0.5
-    const float hx = f32mul(f32div(f32sub(f32sub(ex, s.lvx), f32sub(tvx, s.ltx)), dt32), 0.5f);
-    const float hy = f32mul(f32div(f32sub(f32sub(ey, s.lvy), f32sub(tvy, s.lty)), dt32), 0.5f);
-    const float hz = f32mul(f32div(f32sub(f32sub(ez, s.lvz), f32sub(tvz, s.ltz)), dt32), 0.5f);
+    const float hx = f32mul(div_ctrl_dt(f32sub(f32sub(ex, s.lvx), f32sub(tvx, s.ltx)), dt32, K), 0.5f);
+    const float hy = f32mul(div_ctrl_dt(f32sub(f32sub(ey, s.lvy), f32sub(tvy, s.lty)), dt32, K), 0.5f);
+    const float hz = f32mul(div_ctrl_dt(f32sub(f32sub(ez, s.lvz), f32sub(tvz, s.ltz)), dt32, K), 0.5f);
     s.dvx = (double)hx + s.dvx * 0.5; s.dvy = (double)hy + s.dvy * 0.5; s.dvz = (double)hz + s.dvz * 0.5;
     s.lvx = ex; s.lvy = ey; s.lvz = ez;       // :64
     s.ltx = tvx; s.lty = tvy; s.ltz = tvz;    // :65

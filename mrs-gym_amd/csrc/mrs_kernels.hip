@@ -832,7 +832,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     s.ivx = r1.w; s.ivy = r2.x; s.ivz = r2.y;
                     s.lvx = r2.z; s.lvy = r2.w; s.lvz = r3.x;
                     s.ltx = r3.y; s.lty = r3.z; s.ltz = r3.w;
-                    ta = vel_control_accel(P, s, o0, act[0], act[1], act[2]);
+                    ta = vel_control_accel(P, A.rc, s, o0, act[0], act[1], act[2]);
                     if (KO_KEEP(4)) {
                         g[T] = make_float4((float)s.dvx, (float)s.dvy, (float)s.dvz, (float)s.ivx);
                         g[2 * T] = make_float4((float)s.ivy, (float)s.ivz, s.lvx, s.lvy);
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             for (int k = 0; k < 4; ++k) {
                 double h = p[2] + (Rb.m20 * P.prop_x[k] + Rb.m21 * P.prop_y[k] + Rb.m22 * P.prop_z[k]);
                 h = h < A.hclip ? A.hclip : h; // :77
-                const double ratio = P.prop_radius * rcp64(4 * h); // h >= hclip > 0
+                const double ratio = P.prop_radius * rcp64_coarse(4 * h); // h >= hclip > 0; 1e-14 relative on a term that is ~1e-4 of the thrust
                 double g;
                 if (ACT == MRS_ACT_SET_SPEEDS) {
                     const float sq = f32mul(s32[k], s32[k]);
@@ -1697,6 +1697,13 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
     }
     A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
     A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf); A.rc.inv_dt = 1.0 / h->P.dt;
+    {
+        const float dt32 = (float)h->P.ctrl_dt;
+        uint32_t bits;
+        memcpy(&bits, &dt32, sizeof(bits));
+        A.rc.inv_ctrl_dt32 = (float)(1.0 / (double)dt32); // RN32(RN64(1 / dt32)) = RN32(1 / dt32): 53 >= 2 * 24 + 2
+        A.rc.ctrl_div_fast = std::isnormal(dt32) && (bits & 0x7FFFFFu) != 0x7FFFFFu && std::isnormal(A.rc.inv_ctrl_dt32);
+    }
     const int D = mrs_obs_dim(obs_fields, n_obs);
     if (D < 0) return fail(MRS_E_ARG, "bad observation field list");
     A.n_obs = n_obs; A.D = D;

@@ -1,0 +1,24 @@
+"""mrs_device.hpp:div_ctrl_dt -- float32 division by the controller's DT as multiply + two fused multiply-adds -- is the
+correctly rounded quotient (QuadControl.py:62 divides float32 by DT).  tools/divcheck.py is the exhaustive form (all 3.8e9
+finite x, a minute); here: 4M random bit patterns plus the neighbourhoods of powers of two, for the default DT and two more."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("dt", [0.01, 0.005, 0.02])
+def test_fma_division_by_ctrl_dt_is_correctly_rounded(dt):
+    d = np.float32(dt)
+    r = np.float32(1.0 / np.float64(d))
+    assert (np.frombuffer(d.tobytes(), np.uint32)[0] & 0x7FFFFF) != 0x7FFFFF      # the kernel's ctrl_div_fast condition
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 1 << 32, 1 << 22, dtype=np.uint64).astype(np.uint32)
+    edge = (np.arange(1, 254, dtype=np.uint32)[:, None] << np.uint32(23)) + np.arange(-64, 64, dtype=np.int64)[None, :].astype(np.uint32)
+    x = np.concatenate([bits, edge.ravel(), edge.ravel() | np.uint32(1 << 31)]).view(np.float32)
+    x = x[np.isfinite(x)]
+    x64, d64, r64 = x.astype(np.float64), np.float64(d), np.float64(r)
+    with np.errstate(all="ignore"):
+        want = (x64 / d64).astype(np.float32)
+        q0 = (x64 * r64).astype(np.float32)
+        q1 = (q0.astype(np.float64) + (x64 - d64 * q0.astype(np.float64)) * r64).astype(np.float32)
+    ok = np.isfinite(want) & (np.abs(want) > 1e-30)
+    assert np.array_equal(q1[ok], want[ok])
