@@ -383,9 +383,10 @@ MRS_DEV void attitude_control(const MrsParams &P, const Recips &K, Pid &s, const
     s.ioy = clampd(s.ioy - ey * dt, -1., 1.);
     s.ioz = clampd(s.ioz - ez * dt, -1500., 1500.);
     // :112-115  P=(7e4,7e4,6e4) I=(0,0,500) D=(2e4,2e4,1.2e4), angvel_e = 0 - angvel
-    const double tx = clampd(-(70000. * ex) + 0. * s.iox + 20000. * (0.0 - (double)o.wx), -3200., 3200.);
-    const double ty = clampd(-(70000. * ey) + 0. * s.ioy + 20000. * (0.0 - (double)o.wy), -3200., 3200.);
-    const double tz = clampd(-(60000. * ez) + 500. * s.ioz + 12000. * (0.0 - (double)o.wz), -3200., 3200.);
+    // (the x and y integral gains are zero: "+ 0 * integral" is dropped -- the integrals are clamped, hence finite)
+    const double tx = clampd(-(70000. * ex) - 20000. * (double)o.wx, -3200., 3200.);
+    const double ty = clampd(-(70000. * ey) - 20000. * (double)o.wy, -3200., 3200.);
+    const double tz = clampd(-(60000. * ez) + 500. * s.ioz - 12000. * (double)o.wz, -3200., 3200.);
     double thrust = 0.;
     if (nta != 0) { // :117-122
         const double cosang = (ta.x * rn) * R.m02 + (ta.y * rn) * R.m12 + (ta.z * rn) * R.m22;
@@ -598,7 +599,7 @@ MRS_DEV bool needs_contact(int enable_contact, double park_z, double pz)
     return enable_contact && !(pz > park_z);
 }
 
-MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const double q[4], double v[3], double w[3],
+MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const M3 &R, double v[3], double w[3],
                                 V3 fb_ext, V3 tb_ext)
 {
     // btMultiBody's articulated-body pass for a floating base (oracle/mrs_oracle.c:orc_integrate follows it term by term):
@@ -606,7 +607,7 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const doubl
     // The Coriolis term cancels and |vb| = |v|, so the linear part is formed in the world frame directly:
     //   vdot = R fb / m + g - k_l (1 + |v|) v
     // (identical up to float64 rounding, 1e-16 relative; ~25 float64 instructions fewer).  The angular part needs wb.
-    const M3 R = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+    // R = quat_to_matrix_bullet(q): the caller has it already for the ground effect
     const V3 vw = v3(v[0], v[1], v[2]);
     const V3 wb = mulT(R, v3(w[0], w[1], w[2]));
     // |v|, |w| only scale the quadratic damping term k |v| v (k = 0.04): float32 square roots (1e-7 relative on a

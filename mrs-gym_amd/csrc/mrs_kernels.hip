@@ -753,6 +753,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     }
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
+        M3 Rb; // quat_to_matrix_bullet(q): prop heights of the ground effect, then the velocity integration
         // ---- downwash (Quadcopter.py:99-115): O(N) broadcast reads of the env's LDS tile per lane.
         // Runs FIRST, while only the 13 state words are live: the controller's registers (PID memory,
         // rotation matrices) do not have to survive the 64-iteration loop, which is what keeps the
@@ -905,8 +906,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 zt = ((-t[0] + t[1]) - t[2]) + t[3];
             }
             // ---- Quadcopter.dynamics ground effect (Quadcopter.py:70-87)
-            const M3 Rb = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+            Rb = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
             const bool gnd_on = (ob.roll < (float)(kPi / 2)) && (ob.pitch < (float)(kPi / 2)); // :80 np.abs(bool)
+            const double gcoef = gnd_on ? P.gnd_eff_coeff : 0.0; // switched once, not per rotor
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 double h = p[2] + (Rb.m20 * P.prop_x[k] + Rb.m21 * P.prop_y[k] + Rb.m22 * P.prop_z[k]);
@@ -915,11 +917,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 double g;
                 if (ACT == MRS_ACT_SET_SPEEDS) {
                     const float sq = f32mul(s32[k], s32[k]);
-                    g = (double)f32mul(f32mul(sq, (float)P.kf), (float)P.gnd_eff_coeff) * (ratio * ratio);
+                    g = (double)f32mul(f32mul(sq, (float)P.kf), (float)gcoef) * (ratio * ratio);
                 } else {
-                    g = ((rpm[k] * rpm[k]) * P.kf) * P.gnd_eff_coeff * (ratio * ratio);
+                    g = ((rpm[k] * rpm[k]) * P.kf) * gcoef * (ratio * ratio);
                 }
-                const double f = F[k] + (gnd_on ? g : 0.0);
+                const double f = F[k] + g;
                 fb.z += f;
                 tb.x += P.prop_y[k] * f;   // r x (0,0,f) at the prop link COM (cf2x.urdf:42-78)
                 tb.y += -P.prop_x[k] * f;
@@ -936,7 +938,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             fb.z += downwash_acc;
         }
         TL(22); // rotor forces, ground effect, drag
-        integrate_velocity(A.P, A.rc, q, v, w, fb, tb);
+        if (ACT == MRS_ACT_NONE) Rb = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+        integrate_velocity(A.P, A.rc, Rb, v, w, fb, tb);
     }
     // ---- quad-quad contact on the unconstrained velocities (only envs whose flag is set; see StepArgs.pair_flag).  The
     // agents' float32 velocities go through the position tile's spare space: N = 64 and the multi-wave ring keep every
