@@ -511,6 +511,46 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
     return -(dkeep + (double)wave_ror1(trav));
 }
 
+// Envs of N = 128, 192, 256 (B = N/64 waves, one 64-agent BLOCK of the env per wave, each block with an N = 64 tile of its
+// own): a wave runs downwash_ring64 on its own block and takes the pairs between blocks from here.  Lane l meets the
+// other block's agents (l + k) mod 64, k = K-1 .. 0 (tp = that block's tile + l + o, o = the lane offset of k = 0): its own
+// terms are summed as in downwash_ring64, the other block's terms travel (wave_ror1) and end up, after the k = 0 pass, in
+// the lane whose number is the receiving agent's (less o) -- ONE LDS word per lane handed to the other wave after the
+// loop, where the ring over all N agents (below, any other N) hands over one word per pair.
+//   K = 64: every pair of the two blocks (blocks b and b+1; the wave of b does them all)
+//   K = 32: half of them (blocks b and b + B/2, B even: the lower block takes k = 0..31, the upper one, with o = 1, k = 1..32
+//           of ITS lanes = the other half)
+// Returns the sum of the terms this lane keeps (magnitudes), trav_out = the sum for agent (lane + o) mod 64 of the other block.
+template <int K>
+__device__ __forceinline__ double downwash_cross(const float *tp, float mx_, float my_, float mz_, const DownwashRegs &dr, float &trav_out)
+{
+    const f2 mx = splat(mx_), my = splat(my_), mz = splat(mz_);
+    const auto mine_of = [](float m, float rz, float d2) { return (rz > 0.f && d2 < 100.f) ? m : 0.f; };
+    const auto theirs_of = [](float m, float rz, float d2) { return (rz < 0.f && d2 < 100.f) ? m : 0.f; };
+    float trav = 0.f;
+    double dkeep = 0.;
+    const float *t = tp + (K - 8);
+#pragma unroll 1
+    for (int it = 0; it < K / 8; ++it, t -= 8) { // eight lane distances = four packed passes per trip, k descending
+        TILE64_Z(t);
+        f2 keep = {0.f, 0.f};
+#pragma unroll
+        for (int k = 6; k >= 0; k -= 2) {
+            f2 rx, ry, rz;
+            tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+            const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
+            const f2 m = downwash_mag2_pk(d2, rz, dr);
+            trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
+            trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
+            keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+            asm volatile("" : "+v"(keep));
+        }
+        dkeep += (double)f32add(keep.x, keep.y);
+    }
+    trav_out = trav;
+    return dkeep;
+}
+
 // Quad-quad contact of lane i with one other agent (oracle/mrs_oracle.c:pair_contact, the same float32 operations): the
 // centres' difference r = p_i - p_j, both unconstrained velocities as float32; adds this lane's half of the correction.
 __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, float ry, float rz, float ux, float uy, float uz, float dv[3])
@@ -641,9 +681,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // an env that spans several waves (64 < N <= 256, fused kernel) runs the symmetric ring below on the same kind of
     // tile: three arrays of 2N floats per env, every coordinate twice, so that neighbours k and k+1 of a lane are one
     // ds_read2_b32 at an un-wrapped index (6N floats per env; epb * N <= BLOCK, and the tile region holds 8 * BLOCK)
-    const bool ring = !MRS_EXACT_F32 && FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
+    // N = 128, 192, 256: one N = 64 tile per wave (= per 64-agent block of the env), see downwash_cross
+    const bool multi = !MRS_EXACT_F32 && FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
+    const bool blk = multi && (AN & 63) == 0;
+    const bool ring = multi && !blk;
     float *const ring_x = reinterpret_cast<float *>(lds_tile) + el * 6 * AN;
-    if (tile_soa) tile64_write(lds_tile, el, i, (float)p[0], (float)p[1], (float)p[2]);
+    if (tile_soa || blk) tile64_write(lds_tile, tid >> 6, tid & 63, (float)p[0], (float)p[1], (float)p[2]);
     else if (ring) {
         if (live) {
             ring_x[i] = ring_x[AN + i] = (float)p[0]; ring_x[2 * AN + i] = ring_x[3 * AN + i] = (float)p[1];
@@ -700,6 +743,34 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // (Round 3 experiment, removed: the handed-over terms ADDED into one LDS word per receiving agent -- 64-bit fixed point, so
     // that the sum does not depend on the order of arrival -- instead of laid out per ring distance and summed after a
     // barrier per eight distances: N = 256 x 1024 envs 66.9 against 61.8 us per step, N = 128: 40.8 against 38.1.)
+    if (blk && KO_KEEP(8)) {
+        const int lane = tid & 63, wt = tid >> 6, nb = AN >> 6, b = i >> 6; // wt - b = the tile of the env's first block
+        float *const my_tile = tile64(lds_tile, wt);
+        // the terms from the other waves arrive in the 128 floats a tile leaves free behind its three arrays
+        if (doit) {
+            const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
+            downwash_acc = downwash_ring64(my_tile + lane, mx, my, mz, lane << 2, A.dc, [](int) {});
+            const DownwashRegs dr = downwash_regs(A.dc);
+            if (nb >= 3) { // every pair with the next block
+                float *const ot = tile64(lds_tile, wt - b + (b + 1 == nb ? 0 : b + 1));
+                float trav;
+                downwash_acc -= downwash_cross<64>(ot + lane, mx, my, mz, dr, trav);
+                ot[384 + lane] = trav;
+            }
+            if (!(nb & 1)) { // half of the pairs with the block opposite, which takes the other half
+                const int hb = nb >> 1, o = b >= hb ? 1 : 0;
+                float *const ot = tile64(lds_tile, wt - b + (b >= hb ? b - hb : b + hb));
+                float trav;
+                downwash_acc -= downwash_cross<32>(ot + lane + o, mx, my, mz, dr, trav);
+                ot[448 + ((lane + o) & 63)] = trav;
+            }
+        }
+        __syncthreads();
+        if (doit) {
+            if (nb >= 3) downwash_acc -= (double)my_tile[384 + lane];
+            if (!(nb & 1)) downwash_acc -= (double)my_tile[448 + lane];
+        }
+    }
     constexpr int RING_R = 8;
     if (ring && KO_KEEP(8)) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
@@ -758,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // Runs FIRST, while only the 13 state words are live: the controller's registers (PID memory,
         // rotation matrices) do not have to survive the 64-iteration loop, which is what keeps the
         // kernel at 4 resident waves per SIMD.
-        if (ACT != MRS_ACT_NONE && !ring && KO_KEEP(8)) {
+        if (ACT != MRS_ACT_NONE && !multi && KO_KEEP(8)) {
             const float4 *tile_env = lds_tile + el * AN;
             const DownwashConst &dc = A.dc;
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
@@ -952,8 +1023,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         const bool mine = doit && pf != 0;
         const bool any = n64 ? (__builtin_amdgcn_ballot_w64(mine) != 0) : (__syncthreads_or(mine) != 0);
         if (any) {
-            float *const t64 = tile64(lds_tile, el);
-            if (tile_soa) { t64[64 + i] = (float)v[0]; t64[192 + i] = (float)v[1]; t64[320 + i] = (float)v[2]; }
+            float *const t64 = tile64(lds_tile, tid >> 6); // N = 64: the env's tile; blk: this wave's block of it
+            if (tile_soa || blk) { const int ln = tid & 63; t64[64 + ln] = (float)v[0]; t64[192 + ln] = (float)v[1]; t64[320 + ln] = (float)v[2]; }
             else if (ring) { if (live) { ring_x[AN + i] = (float)v[0]; ring_x[3 * AN + i] = (float)v[1]; ring_x[5 * AN + i] = (float)v[2]; } }
             else lds_tile[BLOCK + tid] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.f);
             if (n64) wave_lds_sync(); else __syncthreads();
@@ -972,6 +1043,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 auto partner = [&](int j) {
                     float qx, qy, qz, wx, wy, wz;
                     if (tile_soa) { qx = t64[j]; qy = t64[128 + j]; qz = t64[256 + j]; wx = t64[64 + j]; wy = t64[192 + j]; wz = t64[320 + j]; }
+                    else if (blk) { const float *tj = t64 + ((j >> 6) - (i >> 6)) * 512 + (j & 63); qx = tj[0]; qy = tj[128]; qz = tj[256]; wx = tj[64]; wy = tj[192]; wz = tj[320]; }
                     else if (ring) { qx = ring_x[j]; qy = ring_x[2 * AN + j]; qz = ring_x[4 * AN + j]; wx = ring_x[AN + j]; wy = ring_x[3 * AN + j]; wz = ring_x[5 * AN + j]; }
                     else { const float4 a = lds_tile[el * AN + j], b = lds_tile[BLOCK + el * AN + j]; qx = a.x; qy = a.y; qz = a.z; wx = b.x; wy = b.y; wz = b.z; }
                     pair_contact_term(A, f32sub(px, qx), f32sub(py, qy), f32sub(pz, qz), f32sub(vx, wx), f32sub(vy, wy), f32sub(vz, wz), dv);

@@ -460,7 +460,7 @@ def test_full_size_bench_workload_properties():
     assert np.array_equal(bits[clear], ((d <= R) & ~np.eye(N, dtype=bool)[None])[clear])
 
 
-@pytest.mark.parametrize("N", [2, 63, 65, 129, 200, 257, 1000])
+@pytest.mark.parametrize("N", [2, 63, 65, 128, 129, 192, 200, 256, 257, 1000])
 def test_awkward_swarm_sizes_match_oracle(N):
     """Workgroup tails (N not dividing 256), the LDS ring exchange for envs that span several waves (odd and even
     N in (64, 256]) and the 1024-thread three-launch path, each through ground contact: 25 steps of three
