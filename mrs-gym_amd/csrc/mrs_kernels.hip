@@ -416,6 +416,148 @@ __device__ __forceinline__ void adj64_flag(const StepArgs &A, const float *t, fl
     if (lane == 0) A.pair_flag[e] = flag;
 }
 
+// ---- N = 128, 192, 256 (256-thread workgroups): an env is nb = N/64 waves, each wave one 64-agent block of it with an
+// N = 64 tile of its own, and every unordered pair is tested ONCE -- own block: adj64_pass; blocks b and b+1: the wave of b
+// (adj_cross<64>); blocks b and b + nb/2 (nb even): each of the two waves half of the pairs (adj_cross<32>, see
+// downwash_cross for the split).  What the loop costs is LDS bandwidth before arithmetic (three ds_read2_b32 = 12 LDS cycles
+// per two pairs, sixteen waves per CU on one LDS): 128 tests per lane instead of the 256 of adjacency_row.
+// Lane l meets the other block's lanes (l + k) mod 64, k descending (tp = that block's tile + l + o).  Its own verdicts are
+// shifted into own[] in that order (bit k - 32 of own[1], bit k of own[0]: see adjacency_row for the sign-bit verdict);
+// the other lane's copy travels (wave_ror1 ahead of every shift): after the k = 32 (k = 0) pass, the word in lane x holds,
+// at the same bit positions, the verdicts of the other block's lane x + 32 (x), and is handed to that wave through LDS.
+template <int K, bool ROWS>
+__device__ __forceinline__ void adj_cross(const float *tp, float mex, float mey, float mez, f2 thr_up2, uint32_t own[2], uint32_t trav[2], float &dmin)
+{
+    const f2 mx = splat(mex), my = splat(mey), mz = splat(mez);
+    const float *t = tp + (K - 8);
+#pragma unroll
+    for (int ph = K / 32 - 1; ph >= 0; --ph) {
+        uint32_t ow = 0, tr = 0;
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it, t -= 8) {
+            TILE64_Z(t);
+#pragma unroll
+            for (int k = 6; k >= 0; k -= 2) {
+                f2 rx, ry, rz;
+                tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+                const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                if (ROWS) {
+                    const f2 sg = pk_sub(d2, thr_up2);
+                    ow = __builtin_amdgcn_alignbit(ow, __float_as_uint(sg.y), 31);
+                    tr = __builtin_amdgcn_alignbit(wave_ror1(tr), __float_as_uint(sg.y), 31);
+                    ow = __builtin_amdgcn_alignbit(ow, __float_as_uint(sg.x), 31);
+                    tr = __builtin_amdgcn_alignbit(wave_ror1(tr), __float_as_uint(sg.x), 31);
+                }
+                dmin = __builtin_fminf(__builtin_fminf(dmin, d2.x), d2.y);
+            }
+        }
+        if (ROWS) { own[ph] = ow; trav[ph] = tr; }
+    }
+}
+// verdicts received "about lane m - k at bit k"  ->  relative column bits of lane m (bit (64 - k) mod 64)
+__device__ __forceinline__ uint64_t adj_mirror64(uint64_t x) { return (__builtin_bitreverse64(x) << 1) | (x & 1ull); }
+__device__ __forceinline__ uint64_t adj_rotl64(uint64_t x, int n) { return n ? ((x << n) | (x >> (64 - n))) : x; }
+
+// One pass over the env's pairs for one squared-distance threshold: the lane's nb row words (word c = the agents of block c),
+// the other waves' verdicts through the exchange words.  Contains a workgroup barrier when rows is set (uniform).
+// rows = false: ones - eye, only dmin is computed (if wanted).  The tiles must hold the positions.
+struct BlockIds { int nb, b, next, prev, opp, o; };
+template <int BLOCK>
+__device__ __forceinline__ void adj_blocks_pass(float4 *lds_tile, int tid, bool live, const BlockIds &B, float4 mine, float thr_s, bool rows, bool want_min,
+                                                uint64_t word[4], float &dmin)
+{
+    const int lane = tid & 63, wt = tid >> 6, nb = B.nb, b = B.b, o = B.o; // wt - b = the tile of the env's first block
+    uint32_t *const my_x = reinterpret_cast<uint32_t *>(tile64(lds_tile, wt)); // exchange words 384 + lane, 448 + lane: the tile's spare quarter
+    uint32_t *const x3 = reinterpret_cast<uint32_t *>(lds_tile + 2 * BLOCK);    // the third one: behind the tiles
+    uint64_t r_own = ~(1ull << lane), rel_next = ~0ull, rel_prev = ~0ull, rel_opp = ~0ull; // COMM_RANGE = inf: ones - eye
+    if (live && (rows || want_min)) {
+        adj64_pass(tile64(lds_tile, wt) + lane, mine.x, mine.y, mine.z, thr_s, rows, want_min, lane, r_own, dmin);
+        float thr = thr_s;
+        asm volatile("" : "+v"(thr));
+        f2 thr_up2 = splat(__uint_as_float(__float_as_uint(thr) + (thr >= 0.f ? 1u : 0u)));
+        asm volatile("" : "+v"(thr_up2));
+        if (nb >= 3) {
+            float *const ot = tile64(lds_tile, wt - b + B.next);
+            uint32_t own[2] = {~0u, ~0u}, trav[2] = {0u, 0u};
+            if (rows) adj_cross<64, true>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            else adj_cross<64, false>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            rel_next = ((uint64_t)own[1] << 32) | own[0];
+            if (rows) {
+                uint32_t *const ox = reinterpret_cast<uint32_t *>(ot);
+                ox[384 + ((lane + 32) & 63)] = trav[1]; ox[448 + lane] = trav[0];
+            }
+        }
+        if (!(nb & 1)) {
+            float *const ot = tile64(lds_tile, wt - b + B.opp);
+            uint32_t own[2] = {~0u, ~0u}, trav[2] = {0u, 0u};
+            if (rows) adj_cross<32, true>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            else adj_cross<32, false>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            if (rows) {
+                rel_opp = (uint64_t)own[0] << o;
+                x3[(wt - b + B.opp) * 64 + ((lane + o) & 63)] = trav[0];
+            }
+        }
+    }
+    if (rows) { // uniform: the threshold is the launch's
+        __syncthreads();
+        if (live) {
+            if (nb >= 3) rel_prev = adj_mirror64(((uint64_t)my_x[384 + lane] << 32) | my_x[448 + lane]);
+            if (!(nb & 1)) rel_opp |= adj_mirror64((uint64_t)x3[wt * 64 + lane] << (1 - o));
+        }
+    }
+    word[b] = r_own;
+    if (nb >= 3) { word[B.next] = adj_rotl64(rel_next, lane); word[B.prev] = adj_rotl64(rel_prev, lane); }
+    if (!(nb & 1)) word[B.opp] = adj_rotl64(rel_opp, lane);
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
+                                                 uint64_t *row, float4 mine, int e)
+{
+    const bool want_hit = A.pair_flag != nullptr;
+    BlockIds B;
+    B.nb = A.N >> 6; B.b = i >> 6;
+    const int hb = B.nb >> 1;
+    B.o = B.b >= hb ? 1 : 0; B.opp = B.b >= hb ? B.b - hb : B.b + hb; B.next = B.b + 1 == B.nb ? 0 : B.b + 1; B.prev = B.b ? B.b - 1 : B.nb - 1;
+    tile64_write(lds_tile, tid >> 6, tid & 63, mine.x, mine.y, mine.z);
+    __syncthreads();
+    float dmin = __builtin_huge_valf();
+    uint64_t word[4];
+    adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, thr_s, !comm_inf, want_hit, word, dmin);
+    if (row && live && KO_KEEP(2)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < B.nb) st<2>(row + c, word[c]);
+    }
+    if (want_hit) {
+        // quad-quad contact range: a pair is seen by one of its two lanes.  An env with a hit (a few per cent of them once bodies
+        // lie on the ground side by side) notes every agent's partners: the same pass again with the contact range as the
+        // threshold -- the tiles still hold the positions; the barrier of the vote separates the two uses of the exchange words
+        if (__syncthreads_or(live && dmin <= A.pair_rc2)) {
+            float unused = 0.f;
+            adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, A.pair_rc2, true, false, word, unused);
+            bool hit = false;
+            if (live) {
+                unsigned long long *const hrow = A.pair_rows + ((size_t)e * A.N + i) * A.W;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < B.nb) { hrow[c] = word[c]; hit |= word[c] != 0; }
+            }
+            // the env's flag: its waves vote through the first exchange word of their tiles (dead after the pass's barrier)
+            __syncthreads();
+            uint32_t *const vote = reinterpret_cast<uint32_t *>(tile64(lds_tile, tid >> 6)) + 384;
+            const bool wave_hit = __builtin_amdgcn_ballot_w64(hit) != 0;
+            if ((tid & 63) == 0) vote[0] = wave_hit ? 1u : 0u;
+            __syncthreads();
+            if (live && i == 0) {
+                bool any = false;
+                for (int c = 0; c < B.nb; ++c) any |= reinterpret_cast<uint32_t *>(tile64(lds_tile, (tid >> 6) + c))[384] != 0;
+                A.pair_flag[e] = any ? MRS_PAIR_ROWS : 0;
+            }
+        } else if (live && i == 0) A.pair_flag[e] = 0;
+    }
+}
+
 // COMM_RANGE adjacency of the workgroup's envs from their CURRENT positions (`mine` per lane), staged through
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 // Also (A.pair_flag): notes per env whether any pair of it is within quad-quad contact range of these positions -- the
@@ -425,6 +567,10 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                                                 uint64_t *row, float4 mine, int e)
 {
     const bool n64 = A.N == 64;
+    if (BLOCK == 256 && A.N > 64 && (A.N & 63) == 0) { // 128, 192, 256
+        adjacency_blocks<BLOCK>(A, thr_s, comm_inf, lds_tile, tid, el, i, live, row, mine, e);
+        return;
+    }
     const bool want_hit = A.pair_flag != nullptr;
     int *const hit_flag = reinterpret_cast<int *>(lds_tile) + 3 * BLOCK; // generic N: one word per env slot, behind the three arrays
     if (!n64 && want_hit && tid < A.epb) hit_flag[tid] = 0;
@@ -1907,7 +2053,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
 static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)
 {
     const int grid = (h->E + h->epb - 1) / h->epb;
-    const size_t lds = 2 * (size_t)h->block * sizeof(float4);
+    const size_t lds = 2 * (size_t)h->block * sizeof(float4) + 256 * sizeof(int); // tile + adjacency_blocks' third exchange word
     if (h->block == 256) hipLaunchKernelGGL((k_observe_adj<256>), dim3(grid), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_observe_adj<1024>), dim3(grid), dim3(1024), lds, st, A);
     hipError_t e = hipGetLastError();

@@ -215,6 +215,41 @@ def test_adjacency_golden_bit_exact(golden_dir):
         assert np.array_equal(got.astype(np.uint8), want), Rk
 
 
+@pytest.mark.parametrize("N", [128, 192, 256])
+def test_adjacency_of_multi_wave_envs_bit_exact(N):
+    """N = 128, 192, 256: an env is 2..4 waves and every unordered pair is tested once (adjacency_blocks: own block, the
+    next block, half of the opposite block; the other wave's verdicts arrive through LDS).  Rows against the oracle's
+    float32 all-pairs matrix, bit for bit, for a dense cloud (most pairs near the threshold), three ranges and
+    COMM_RANGE = inf, through the standalone entry and at the end of a step; E odd: N = 128 leaves half a workgroup empty."""
+    import mrsgym_amd
+    E = 5
+    rng = np.random.default_rng(N)
+    pos = rng.uniform(-2.0, 2.0, (E, N, 3)).astype(np.float32)
+    pos[..., 2] += 30.0
+    pos[1, 7] = pos[1, N - 5] + np.float32(0.25)         # planted: exactly representable offsets, d = sqrt(3)/4
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=z, vel=z, angvel=z)
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    dense = torch.zeros(E, N, N, device="cuda:0")
+    for R in (0.7, 2.5, float(np.sqrt(np.float32(3)) / 4), float("inf")):
+        adj.fill_(-1)
+        sh.adjacency(adj, R)
+        sh.adjacency_expand(adj, dense)
+        want = np.stack([oracle.adjacency(pos[e], R) for e in range(E)])
+        assert np.array_equal(dense.cpu().numpy(), want), R
+    sw = oracle.OracleSwarm(E, N, nthreads=8)
+    sw.set_state(pos=pos.astype(np.float64), euler=z, vel=z.astype(np.float64), angvel=z.astype(np.float64))
+    acts = ActionStream("set_control", E, N, pos, seed=5)
+    for t in range(3):
+        a = acts(t)
+        sh.step(torch.from_numpy(a).cuda(), "set_control", adj_out=adj, comm_range=2.5)
+        sw.step(a, "set_control")
+    sh.adjacency_expand(adj, dense)
+    p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
+    assert np.array_equal(dense.cpu().numpy(), np.stack([oracle.adjacency(p32[e], 2.5) for e in range(E)]))
+
+
 def test_reference_trajectories_F6(golden_dir):
     """The reference's own MRS.step() trajectories (fake-bullet harness), teacher-forced on the GPU."""
     import glob
@@ -521,7 +556,7 @@ def test_workgroup_size_does_not_change_results(atype):
 
 
 @pytest.mark.parametrize("with_adj", [True, False])
-@pytest.mark.parametrize("E,N", [(3, 64), (5, 12), (2, 130), (2, 300)])
+@pytest.mark.parametrize("E,N", [(3, 64), (5, 12), (2, 130), (3, 128), (2, 256), (2, 300)])
 def test_quad_quad_contact_matches_oracle(E, N, with_adj):
     """Row G, second half (the build's own model, oracle: pair_contact): pairs on collision courses -- head-on, crossing
     vertically, glancing -- among agents that stay far apart, for the one-wave env (N = 64), several envs per wave
@@ -630,7 +665,7 @@ def test_quad_quad_contact_after_a_masked_set_state():
     assert np.linalg.norm(sw.pos[1, 9] - sw.pos[1, 30]) > 0.12 - 1e-5
 
 
-@pytest.mark.parametrize("E,N", [(3, 64), (4, 12), (2, 130), (2, 300)])
+@pytest.mark.parametrize("E,N", [(3, 64), (4, 12), (2, 130), (3, 192), (2, 256), (2, 300)])
 def test_quad_quad_several_partners_at_once(E, N):
     """An agent squeezed between two others (and a cluster of four) has several contacts in the same step: the adjacency
     pass notes every agent's partners (MRS_PAIR_ROWS, StepArgs.pair_rows) and the step adds one term per partner, in

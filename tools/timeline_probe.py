@@ -17,7 +17,7 @@ sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", want_rpm=True)
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
 acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
 table = [torch.from_numpy(acts(50 * k)).cuda() for k in range(20)]
-obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torch.int64, device="cuda")
+obs = torch.zeros(E, N, sh.D, device="cuda"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda")   # W words per row: N > 64 has several
 names = ["loads+tile+vote", "downwash", "controller", "forces+intvel", "barrier1", "own solve", "barrier2", "pose+store", "obs+adj(end)"]
 for T0 in (200, 800):
     for t in range(T0 if T0 == 200 else 600):

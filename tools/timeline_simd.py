@@ -7,18 +7,22 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tes
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT
 from util_scenarios import ActionStream, grid_spawn
-E, N = 4096, 64
+E, N = int(os.environ.get("E", 4096)), int(os.environ.get("N", 64))
+ATYPE = os.environ.get("ATYPE", "set_target_vel")
 pos, eul = grid_spawn(E, N); z = np.zeros((E, N, 3), np.float32)
 sh = mrsgym_amd.SwarmShard(E, N, "cuda:0", want_rpm=True)
 sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
-acts = ActionStream("set_target_vel", E, N, pos, seed=1000)
+acts = ActionStream(ATYPE, E, N, pos, seed=1000)
 table = [torch.from_numpy(acts(50 * k)).cuda() for k in range(20)]
-obs = torch.zeros(E, N, 6, device="cuda"); adj = torch.zeros(E, N, 1, dtype=torch.int64, device="cuda")
+obs = torch.zeros(E, N, sh.D, device="cuda"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda")
 names = ["loads", "downwash", "controller", "forces", "barrier1", "solve", "barrier2", "pose+store", "obs+adj"]
 for t in range(800):
-    sh.step_ptr(table[(t // 50) % 20], ACT["set_target_vel"], obs.data_ptr(), adj.data_ptr(), 5.0)
+    sh.step_ptr(table[(t // 50) % 20], ACT[ATYPE], obs.data_ptr(), adj.data_ptr(), 5.0)
 torch.cuda.synchronize()
-full = sh.rpm.flatten()[:E * 16].view(E, 16).cpu().numpy().astype(np.float64)
+WPW = 4                                                   # waves per workgroup (256 threads)
+NW = E if N == 64 else -(-E // (256 // N)) * 4            # waves of the launch
+full = sh.rpm.flatten()[:NW * 16].view(NW, 16).cpu().numpy().astype(np.float64)
+E = NW
 hw = full[:, 13].astype(np.int64) | (full[:, 14].astype(np.int64) << 16)
 slot, simd, cu, shid, se, xcc = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, full[:, 15].astype(np.int64)
 t0, t1 = full[:, 11], full[:, 12]
@@ -27,7 +31,7 @@ print("clock64: %.0f ticks per us; waves %d; distinct (xcc,se,sh,cu): %d, SIMDs:
 first = t0.min()
 # absolute time (us, chip-wide clock for the start + the wave's own counter for the phases) of each stamp
 absT = (t0 - first)[:, None] / 100.0 + full[:, :9] / rate
-wg = np.arange(E) // 8
+wg = np.arange(E) // WPW
 print("absolute end of each phase, us after the first wave started: mean [p5 .. p95]")
 for k, nm in enumerate(names):
     c = absT[:, k]
@@ -39,7 +43,7 @@ def spread(groups, col):
         c = absT[g, col]
         out.append(c.max() - c.min())
     return np.array(out)
-wgs = [np.where(wg == w)[0] for w in range(E // 8)]
+wgs = [np.where(wg == w)[0] for w in range(E // WPW)]
 key = xcc * 100000 + se * 10000 + shid * 1000 + cu * 10 + simd
 simds = [np.where(key == k)[0] for k in np.unique(key)]
 cus = [np.where(key // 10 == k)[0] for k in np.unique(key // 10)]
@@ -54,6 +58,16 @@ for c in cus:
     ends.append(sorted(absT[wg == x, 8].max() for x in w))
 ne = np.array([len(x) for x in ends])
 print("workgroups per CU: ", np.bincount(ne))
+cu_end = np.array([x[-1] for x in ends])
+print("CU done: min %.2f  p25 %.2f  median %.2f  p75 %.2f  p95 %.2f  max %.2f us" % (cu_end.min(), *np.percentile(cu_end, [25, 50, 75, 95]), cu_end.max()))
+wend = absT[:, 8]
+print("wave ends: " + "  ".join("p%d %.1f" % (q, np.percentile(wend, q)) for q in (5, 25, 50, 75, 90, 95, 99, 100)))
+late = wend > np.percentile(wend, 95)
+print("the latest 5%% of the waves: phase durations (us) against everybody's:")
+dur = np.diff(np.concatenate([np.zeros((E, 1)), full[:, :9] / rate], 1), axis=1)
+for k, nm in enumerate(names):
+    print("    %-12s late %.2f   all %.2f" % (nm, dur[late, k].mean(), dur[:, k].mean()))
+print("   late waves per xcc:", np.bincount(xcc[late], minlength=8), " wave index in workgroup:", np.bincount(np.arange(E)[late] % WPW, minlength=WPW))
 two = np.array([x for x in ends if len(x) == 2])
 if len(two):
     print("CUs with two workgroups: first ends %.2f us, second %.2f us (mean); last CU done at %.2f" % (two[:, 0].mean(), two[:, 1].mean(), two[:, 1].max()))
