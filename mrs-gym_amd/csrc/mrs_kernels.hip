@@ -460,18 +460,22 @@ __device__ __forceinline__ uint64_t adj_rotl64(uint64_t x, int n) { return n ? (
 
 // One pass over the env's pairs for one squared-distance threshold: the lane's nb row words (word c = the agents of block c),
 // the other waves' verdicts through the exchange words.  Contains a workgroup barrier when rows is set (uniform).
-// rows = false: ones - eye, only dmin is computed (if wanted).  The tiles must hold the positions.
+// rows = false: ones - eye, only the minima are computed (if wanted).  The tiles must hold the positions.
+// dm[0..2] = the smallest squared distance among the lane's pairs in its own block / with the next block / with the block
+// opposite; run (wave-uniform) = which of the three parts to walk at all (bit 0, 1, 2) -- a part left out has no pair within
+// the threshold, its verdicts are zeros.
 struct BlockIds { int nb, b, next, prev, opp, o; };
 template <int BLOCK>
 __device__ __forceinline__ void adj_blocks_pass(float4 *lds_tile, int tid, bool live, const BlockIds &B, float4 mine, float thr_s, bool rows, bool want_min,
-                                                uint64_t word[4], float &dmin)
+                                                int run, uint64_t word[4], float dm[3])
 {
     const int lane = tid & 63, wt = tid >> 6, nb = B.nb, b = B.b, o = B.o; // wt - b = the tile of the env's first block
     uint32_t *const my_x = reinterpret_cast<uint32_t *>(tile64(lds_tile, wt)); // exchange words 384 + lane, 448 + lane: the tile's spare quarter
     uint32_t *const x3 = reinterpret_cast<uint32_t *>(lds_tile + 2 * BLOCK);    // the third one: behind the tiles
     uint64_t r_own = ~(1ull << lane), rel_next = ~0ull, rel_prev = ~0ull, rel_opp = ~0ull; // COMM_RANGE = inf: ones - eye
     if (live && (rows || want_min)) {
-        adj64_pass(tile64(lds_tile, wt) + lane, mine.x, mine.y, mine.z, thr_s, rows, want_min, lane, r_own, dmin);
+        if (run & 1) adj64_pass(tile64(lds_tile, wt) + lane, mine.x, mine.y, mine.z, thr_s, rows, want_min, lane, r_own, dm[0]);
+        else r_own = 0;
         float thr = thr_s;
         asm volatile("" : "+v"(thr));
         f2 thr_up2 = splat(__uint_as_float(__float_as_uint(thr) + (thr >= 0.f ? 1u : 0u)));
@@ -479,8 +483,9 @@ __device__ __forceinline__ void adj_blocks_pass(float4 *lds_tile, int tid, bool 
         if (nb >= 3) {
             float *const ot = tile64(lds_tile, wt - b + B.next);
             uint32_t own[2] = {~0u, ~0u}, trav[2] = {0u, 0u};
-            if (rows) adj_cross<64, true>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
-            else adj_cross<64, false>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            if (!(run & 2)) own[0] = own[1] = 0u;
+            else if (rows) adj_cross<64, true>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dm[1]);
+            else adj_cross<64, false>(ot + lane, mine.x, mine.y, mine.z, thr_up2, own, trav, dm[1]);
             rel_next = ((uint64_t)own[1] << 32) | own[0];
             if (rows) {
                 uint32_t *const ox = reinterpret_cast<uint32_t *>(ot);
@@ -490,8 +495,9 @@ __device__ __forceinline__ void adj_blocks_pass(float4 *lds_tile, int tid, bool 
         if (!(nb & 1)) {
             float *const ot = tile64(lds_tile, wt - b + B.opp);
             uint32_t own[2] = {~0u, ~0u}, trav[2] = {0u, 0u};
-            if (rows) adj_cross<32, true>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
-            else adj_cross<32, false>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dmin);
+            if (!(run & 4)) own[0] = 0u;
+            else if (rows) adj_cross<32, true>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dm[2]);
+            else adj_cross<32, false>(ot + lane + o, mine.x, mine.y, mine.z, thr_up2, own, trav, dm[2]);
             if (rows) {
                 rel_opp = (uint64_t)own[0] << o;
                 x3[(wt - b + B.opp) * 64 + ((lane + o) & 63)] = trav[0];
@@ -521,9 +527,9 @@ __device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s,
     B.o = B.b >= hb ? 1 : 0; B.opp = B.b >= hb ? B.b - hb : B.b + hb; B.next = B.b + 1 == B.nb ? 0 : B.b + 1; B.prev = B.b ? B.b - 1 : B.nb - 1;
     tile64_write(lds_tile, tid >> 6, tid & 63, mine.x, mine.y, mine.z);
     __syncthreads();
-    float dmin = __builtin_huge_valf();
+    float dm[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
     uint64_t word[4];
-    adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, thr_s, !comm_inf, want_hit, word, dmin);
+    adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, thr_s, !comm_inf, want_hit, 7, word, dm);
     if (row && live && KO_KEEP(2)) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -531,11 +537,17 @@ __device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s,
     }
     if (want_hit) {
         // quad-quad contact range: a pair is seen by one of its two lanes.  An env with a hit (a few per cent of them once bodies
-        // lie on the ground side by side) notes every agent's partners: the same pass again with the contact range as the
-        // threshold -- the tiles still hold the positions; the barrier of the vote separates the two uses of the exchange words
-        if (__syncthreads_or(live && dmin <= A.pair_rc2)) {
-            float unused = 0.f;
-            adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, A.pair_rc2, true, false, word, unused);
+        // lie on the ground side by side; a launch lasts as long as its slowest workgroup) notes every agent's partners: the
+        // same pass with the contact range as the threshold, but only the parts of it in which a lane of the wave has seen a
+        // hit -- one of a dozen, typically.  The tiles still hold the positions; the vote's barrier separates the two uses of
+        // the exchange words.
+        float rc2 = A.pair_rc2;
+        asm volatile("" : "+v"(rc2));
+        const int run = (__builtin_amdgcn_ballot_w64(live && dm[0] <= rc2) ? 1 : 0) | (__builtin_amdgcn_ballot_w64(live && dm[1] <= rc2) ? 2 : 0) |
+                        (__builtin_amdgcn_ballot_w64(live && dm[2] <= rc2) ? 4 : 0);
+        if (__syncthreads_or(run)) {
+            float unused[3];
+            adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, rc2, true, false, run, word, unused);
             bool hit = false;
             if (live) {
                 unsigned long long *const hrow = A.pair_rows + ((size_t)e * A.N + i) * A.W;
