@@ -380,13 +380,22 @@ __device__ __forceinline__ void adj64_flag(const StepArgs &A, const float *t, fl
     if (__builtin_amdgcn_ballot_w64(near) != 0) {
         // which of its pairs: neighbours k = 1..31 within range at bit k of hm, the antipode k = 32 in ht
         // (the same float32 operations as the pass, hence the same distances)
+        // Unrolled, two neighbours per pass like the pass itself: the wave is alone on its SIMD by now and the launch waits for
+        // it -- as a rolled loop of 32 dependent LDS round trips this walk was 1.9 us (tools/timeline_simd.py: the seven latest
+        // workgroups of a bench launch were the seven with a flagged env), now the reads are in flight together.
         uint32_t hm = 0;
         bool ht = false;
-#pragma unroll 1
-        for (int k = 1; k <= 32; ++k) {
-            const float rx = f32sub(t[k], mex), ry = f32sub(t[128 + k], mey), rz = f32sub(t[256 + k], mez);
-            const bool in = f32fma(rz, rz, f32fma(ry, ry, f32mul(rx, rx))) <= rc2;
-            if (k < 32) hm |= in ? (1u << k) : 0u; else ht = in;
+        {
+            const f2 mx = splat(mex), my = splat(mey), mz = splat(mez);
+            TILE64_Z(t);
+#pragma unroll
+            for (int k = 1; k < 33; k += 2) {
+                f2 rx, ry, rz;
+                tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+                const f2 d2 = pk_fma(rz, rz, pk_fma(ry, ry, pk_mul(rx, rx)));
+                hm |= d2.x <= rc2 ? (1u << k) : 0u;
+                if (k + 1 < 32) hm |= d2.y <= rc2 ? (1u << (k + 1)) : 0u; else ht = d2.y <= rc2;
+            }
         }
         const int cnt = __builtin_popcount(hm) + (ht ? 1 : 0);
         const uint64_t testers = __builtin_amdgcn_ballot_w64(cnt != 0);

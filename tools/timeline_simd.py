@@ -67,6 +67,17 @@ print("the latest 5%% of the waves: phase durations (us) against everybody's:")
 dur = np.diff(np.concatenate([np.zeros((E, 1)), full[:, :9] / rate], 1), axis=1)
 for k, nm in enumerate(names):
     print("    %-12s late %.2f   all %.2f" % (nm, dur[late, k].mean(), dur[:, k].mean()))
+wg_end = np.array([absT[wg == x, 8].max() for x in range(E // WPW)])
+order = np.argsort(-wg_end)[:12]
+print("the latest workgroups: end (us), then per wave the phase durations " + "/".join(n[:5] for n in names))
+pf = None
+zz = sh.pos[2].view(-1, N).cpu().numpy()
+low = (zz < 0.6).sum(1)                                  # bodies near the ground per env (after the step)
+for x in order:
+    ws = np.where(wg == x)[0]
+    print("  wg %4d end %.2f  xcc %d cu %d" % (x, wg_end[x], xcc[ws[0]], cu[ws[0]]) + ("  near the ground per env: %s" % low[ws] if N == 64 else ""))
+    for w_ in ws:
+        print("      " + " ".join("%5.2f" % d for d in dur[w_]) + "   start %.2f" % ((t0[w_] - first) / 100))
 print("   late waves per xcc:", np.bincount(xcc[late], minlength=8), " wave index in workgroup:", np.bincount(np.arange(E)[late] % WPW, minlength=WPW))
 two = np.array([x for x in ends if len(x) == 2])
 if len(two):
