@@ -78,6 +78,16 @@ for x in order:
     print("  wg %4d end %.2f  xcc %d cu %d" % (x, wg_end[x], xcc[ws[0]], cu[ws[0]]) + ("  near the ground per env: %s" % low[ws] if N == 64 else ""))
     for w_ in ws:
         print("      " + " ".join("%5.2f" % d for d in dur[w_]) + "   start %.2f" % ((t0[w_] - first) / 100))
+widx = np.arange(E) % WPW
+print("wave index in its workgroup x SIMD (number of waves):")
+for k in range(WPW):
+    print("    wave %d: " % k + " ".join("%5d" % ((widx == k) & (simd == j)).sum() for j in range(4)))
+print("phase durations by wave index (us): " + "/".join(n[:5] for n in names))
+for k in range(WPW):
+    print("    wave %d: " % k + " ".join("%5.2f" % dur[widx == k, c].mean() for c in range(9)))
+print("phase durations by SIMD (us):")
+for j in range(4):
+    print("    simd %d: " % j + " ".join("%5.2f" % dur[simd == j, c].mean() for c in range(9)))
 print("   late waves per xcc:", np.bincount(xcc[late], minlength=8), " wave index in workgroup:", np.bincount(np.arange(E)[late] % WPW, minlength=WPW))
 two = np.array([x for x in ends if len(x) == 2])
 if len(two):
