@@ -20,12 +20,18 @@ def shard_range(n_envs_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _forced():
+    """MRS_DIST_FORCE=1: take the collective path with ONE rank too -- the rehearsal of the RCCL leg on a one-GPU box
+    (communicator set-up, all_gather_into_tensor on the side stream, the event hand-shake): tests/test_gpu_dist.py."""
+    return os.environ.get("MRS_DIST_FORCE") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -46,8 +52,9 @@ class ObsAllGather:
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.e_local = int(e_local)
+        self.collective = dist.is_initialized() and (self.world > 1 or _forced())
         # shard sizes of every rank (shard_range hands the remainder of E % world to the low ranks): exchanged once here
-        if self.world > 1:
+        if self.collective:
             mine = torch.tensor([self.e_local], dtype=torch.int64, device=self.device)
             every = [torch.zeros_like(mine) for _ in range(self.world)]
             dist.all_gather(every, mine, group=group)
@@ -83,7 +90,7 @@ class ObsAllGather:
         k = self.k
         self.k = (k + 1) % len(self.out)
         out = self.out[k]
-        if self.world == 1:
+        if not self.collective:
             out.copy_(newest)
             return out
         if self.cuda:
@@ -123,7 +130,7 @@ class ObsAllGather:
 
 def gather_global_state(local, group=None):
     """Concatenate per-rank (E_local, ...) tensors in rank order (tests: 1-GPU vs sharded bitwise equality)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _forced()):
         return local
     world = dist.get_world_size(group)
     mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)

@@ -50,8 +50,9 @@ def main():
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist_product.npz"), joint=np.stack(joint), state=state.cpu().numpy(), adj=adj_all.cpu().numpy(),
                  backend=np.array("nccl" if multi else "gloo"))
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -28,16 +28,22 @@ def _free_port():
     return p
 
 
-def test_two_rank_product_run_equals_single_gpu_bitwise(tmp_path):
+@pytest.mark.parametrize("ranks", [2, 1])
+def test_product_ranks_equal_single_gpu_bitwise(tmp_path, ranks):
+    """ranks = 2: see the module text.  ranks = 1: the same worker as ONE rank, which always sits on RCCL (backend "nccl") --
+    on the one-GPU boxes of this pool the only way the RCCL leg of ObsAllGather / gather_global_state (communicator set-up,
+    all_gather_into_tensor on the side stream, the event hand-shake with the step stream) runs at all."""
     import mrsgym_amd
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    if ranks == 1:
+        env["MRS_DIST_FORCE"] = "1"             # mrsgym_amd.dist: the collective path with one rank
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_product_worker.py"), str(tmp_path), str(E_TOTAL), str(N),
            str(STEPS), ATYPE]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = np.load(os.path.join(str(tmp_path), "dist_product.npz"))
-    if torch.cuda.device_count() >= 2:
+    if torch.cuda.device_count() >= ranks:
         assert str(d["backend"]) == "nccl"      # RCCL carried the gather
     # the same swarm in one process on one GPU
     pos, eul = grid_spawn(E_TOTAL, N)
