@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRS_ABI_VERSION 3
+#define MRS_ABI_VERSION 4
 
 /* error codes (negative) */
 #define MRS_E_ARG (-1)        /* bad argument (NULL, size, unsupported N) */
@@ -110,6 +110,11 @@ typedef struct MrsBuffers {
     uint64_t *adj;    /* (E,N,W) bit-packed newest adjacency rows, W = ceil(N/64), or NULL */
     float *rpm;       /* [4][T]  rotor speeds used by the last step (optional)     */
     uint32_t *status; /* [E]     MRS_STATUS_* bits, OR-ed in (optional)            */
+    float *adj_dense; /* (E,N,N) newest adjacency as the float32 0/1 matrices MRS.calc_A returns (MRS.py:117-124), or NULL.
+                         Needs adj as well.  mrs_step / mrs_adjacency write it from the kernel that builds the rows where an
+                         env is whole wavefronts (N = 64, 128, 192, 256) and the pointer is 16-byte aligned -- 4 N^2 bytes per
+                         env on top of the step's own traffic instead of a second kernel that reads the packed rows back --
+                         and through mrs_adjacency_expand behind the step otherwise (ABI 4) */
 } MrsBuffers;
 
 typedef struct MrsHandle MrsHandle;

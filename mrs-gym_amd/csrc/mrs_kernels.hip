@@ -467,6 +467,27 @@ __device__ __forceinline__ void adj_cross(const float *tp, float mex, float mey,
 __device__ __forceinline__ uint64_t adj_mirror64(uint64_t x) { return (__builtin_bitreverse64(x) << 1) | (x & 1ull); }
 __device__ __forceinline__ uint64_t adj_rotl64(uint64_t x, int n) { return n ? ((x << n) | (x >> (64 - n))) : x; }
 
+// MrsBuffers.adj_dense: the rows of one wave's 64 agents as the float32 0/1 matrix rows the reference returns (MRS.py:117-124),
+// written by the wave that has just built them instead of by a second kernel that reads the packed rows back
+// (mrs_adjacency_expand): the words go through LDS (rl: 64 * WPR words of the wave's own, dead, tile) so that every store
+// instruction is 64 lanes x 16 bytes of one contiguous kilobyte -- lane l of pass q holds the float4 number 64 q + l of the
+// wave's 64 x N chunk.  WPR = words per row = N / 64; dst = the chunk (16-byte aligned, checked by the host).
+template <int WPR>
+__device__ __forceinline__ void dense_rows_store(uint64_t *rl, const uint64_t *word, int lane, float *dst)
+{
+#pragma unroll
+    for (int c = 0; c < WPR; ++c) rl[lane * WPR + c] = word[c];
+    wave_lds_sync();
+    float4 *const d4 = reinterpret_cast<float4 *>(dst);
+    constexpr int C4 = 16 * WPR; // float4 per row
+#pragma unroll 4
+    for (int q = 0; q < C4; ++q) {
+        const int f = 64 * q + lane, r = f / C4, c4 = f - r * C4;
+        const uint32_t nib = (uint32_t)(rl[r * WPR + (c4 >> 4)] >> ((c4 & 15) * 4));
+        d4[f] = make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
+    }
+}
+
 // One pass over the env's pairs for one squared-distance threshold: the lane's nb row words (word c = the agents of block c),
 // the other waves' verdicts through the exchange words.  Contains a workgroup barrier when rows is set (uniform).
 // rows = false: ones - eye, only the minima are computed (if wanted).  The tiles must hold the positions.
@@ -556,13 +577,14 @@ __device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s,
                         (__builtin_amdgcn_ballot_w64(live && dm[2] <= rc2) ? 4 : 0);
         if (__syncthreads_or(run)) {
             float unused[3];
-            adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, rc2, true, false, run, word, unused);
+            uint64_t hw[4];
+            adj_blocks_pass<BLOCK>(lds_tile, tid, live, B, mine, rc2, true, false, run, hw, unused);
             bool hit = false;
             if (live) {
                 unsigned long long *const hrow = A.pair_rows + ((size_t)e * A.N + i) * A.W;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c < B.nb) { hrow[c] = word[c]; hit |= word[c] != 0; }
+                    if (c < B.nb) { hrow[c] = hw[c]; hit |= hw[c] != 0; }
             }
             // the env's flag: its waves vote through the first exchange word of their tiles (dead after the pass's barrier)
             __syncthreads();
@@ -576,6 +598,16 @@ __device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s,
                 A.pair_flag[e] = any ? MRS_PAIR_ROWS : 0;
             }
         } else if (live && i == 0) A.pair_flag[e] = 0;
+    }
+    if (A.b.adj_dense && row) { // uniform.  The tiles are dead once every wave is through the passes above
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(live) != 0) { // whole waves are live or not (N is a multiple of 64)
+            uint64_t *const rl = reinterpret_cast<uint64_t *>(tile64(lds_tile, tid >> 6));
+            float *const dst = A.b.adj_dense + ((size_t)e * A.N + (size_t)(i & ~63)) * A.N;
+            if (B.nb == 4) dense_rows_store<4>(rl, word, tid & 63, dst);
+            else if (B.nb == 3) dense_rows_store<3>(rl, word, tid & 63, dst);
+            else dense_rows_store<2>(rl, word, tid & 63, dst);
+        }
     }
 }
 
@@ -608,6 +640,8 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
             adj64_pass(t, mine.x, mine.y, mine.z, thr_s, !comm_inf, want_hit, lane, r64, dmin);
             if (want_hit) adj64_flag(A, t, mine.x, mine.y, mine.z, lane, e, dmin <= A.pair_rc2);
             if (row && KO_KEEP(2)) st<2>(row, r64);
+            if (row && A.b.adj_dense) // (uniform) the env's matrix, by the env's wave
+                dense_rows_store<1>(reinterpret_cast<uint64_t *>(tile64(lds_tile, el)), &r64, lane, A.b.adj_dense + (size_t)e * 64 * 64);
         }
     } else {
         bool hit = false;
@@ -2001,6 +2035,23 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
 
 extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions, int action_type,
                         const int32_t *obs_fields, int n_obs_fields, double comm_range, void *stream);
+extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int n_matrices, void *stream);
+
+// MrsBuffers.adj_dense: written by the kernel that builds the rows where an env is whole waves (N = 64; N = 128, 192, 256 in
+// 256-thread workgroups) and the matrix is 16-byte aligned; anywhere else by mrs_adjacency_expand behind it.
+static bool dense_in_kernel(const MrsHandle *h, const MrsBuffers *b, bool step_kernel)
+{
+    if (!b->adj_dense || !b->adj || ((uintptr_t)b->adj_dense & 15)) return false;
+    if (h->N == 64) return true;
+    if (h->N > 64 && h->N <= 256 && (h->N & 63) == 0) return ((step_kernel && h->fused) ? h->sblock : h->block) == 256;
+    return false;
+}
+static int dense_behind(MrsHandle *h, const MrsBuffers *b, bool in_kernel, void *stream)
+{
+    if (!b->adj_dense || in_kernel) return 0;
+    if (!b->adj) return fail(MRS_E_ARG, "adj_dense needs the packed rows (adj) as well");
+    return mrs_adjacency_expand(h, b->adj, b->adj_dense, h->E, stream);
+}
 
 // n_substeps consecutive steps from ONE host call: the launches are queued back to back on the stream (the GPU runs
 // them without a gap; what is saved is the caller's per-step work between them).  Keeping the state in registers
@@ -2014,6 +2065,7 @@ extern "C" int mrs_step_n(MrsHandle *h, const MrsBuffers *b, const float *action
     if (n_substeps < 1) return fail(MRS_E_ARG, "mrs_step_n: n_substeps must be >= 1");
     MrsBuffers bb = *b;
     for (int s = 0; s < n_substeps; ++s) {
+        bb.adj_dense = s == n_substeps - 1 ? b->adj_dense : nullptr; // the dense matrices of the last substep only (with its packed rows)
         const int rc = mrs_step(h, &bb, actions ? actions + (long long)s * action_stride : nullptr, action_type, obs_fields, n_obs_fields, comm_range, stream);
         if (rc) return rc;
         if (bb.obs) bb.obs += obs_stride;
@@ -2036,6 +2088,9 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     int rc = fill_common(h, b, obs_fields, n_obs_fields, comm_range, A);
     if (rc) return rc;
     A.actions = actions;
+    const bool want_dense = b->adj_dense && !std::isnan(comm_range);
+    const bool dense_k = want_dense && dense_in_kernel(h, b, true);
+    if (!dense_k) A.b.adj_dense = nullptr;
 #if MRS_KO == -1
     { const char *ko = getenv("MRS_KO"); A.ko = ko ? atoi(ko) : 0; }
 #endif
@@ -2061,7 +2116,7 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
     default: e = launch_step<MRS_ACT_TARGET_ORI>(h, A, st, fused); break;
     }
     if (e != hipSuccess) return hipfail(e, "mrs_step launch");
-    if (fused) return 0;
+    if (fused) return want_dense ? dense_behind(h, b, dense_k, stream) : 0;
     if (h->P.enable_contact) {
         // worst-case grid; blocks beyond the device-side count return at once
         const int T = h->E * h->N;
@@ -2070,8 +2125,11 @@ extern "C" int mrs_step(MrsHandle *h, const MrsBuffers *b, const float *actions,
         e = hipGetLastError();
         if (e != hipSuccess) return hipfail(e, "mrs_step contact launch");
     }
-    if ((A.n_obs > 0 && A.b.obs) || A.do_adj) return launch_observe_adj(h, A, st);
-    return 0;
+    if ((A.n_obs > 0 && A.b.obs) || A.do_adj) {
+        rc = launch_observe_adj(h, A, st);
+        if (rc) return rc;
+    }
+    return want_dense ? dense_behind(h, b, dense_k, stream) : 0;
 }
 
 static int launch_observe_adj(MrsHandle *h, const StepArgs &A, hipStream_t st)
@@ -2102,7 +2160,10 @@ extern "C" int mrs_adjacency(MrsHandle *h, const MrsBuffers *b, double comm_rang
     StepArgs A;
     int rc = fill_common(h, b, nullptr, 0, comm_range, A);
     if (rc) return rc;
-    return launch_observe_adj(h, A, (hipStream_t)stream);
+    const bool dense_k = dense_in_kernel(h, b, false);
+    if (!dense_k) A.b.adj_dense = nullptr;
+    rc = launch_observe_adj(h, A, (hipStream_t)stream);
+    return rc ? rc : dense_behind(h, b, dense_k, stream);
 }
 
 extern "C" int mrs_adjacency_expand(MrsHandle *h, const uint64_t *packed, float *dense, int n_matrices, void *stream)

@@ -194,9 +194,11 @@ class MRS(_EnvBase):
 
     def calc_Ak(self):  # MRS.py:102-110
         slot = self._Apacked.next_slot()
-        self.shard.adjacency(self._Apacked.buf[slot], self.COMM_RANGE)
+        dslot = self._Adense.next_slot() if self._Adense is not None else 0
+        self.shard.adjacency(self._Apacked.buf[slot], self.COMM_RANGE, self._Adense.buf[dslot] if self._Adense is not None else None)
         self._Apacked.committed()
-        self._expand_newest_A()
+        if self._Adense is not None:
+            self._Adense.committed()
         return self.get_Ak()
 
     def _expand_newest_A(self):
@@ -212,11 +214,11 @@ class MRS(_EnvBase):
     def calc_A(self):  # MRS.py:117-124  newest adjacency only, no history side effect
         E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
         packed = torch.zeros(E, N, W, dtype=torch.int64, device=self.device)
-        self.shard.adjacency(packed, self.COMM_RANGE)
         if self.A_FORMAT != "dense":
+            self.shard.adjacency(packed, self.COMM_RANGE)
             return self._squeeze(packed)
         dense = torch.zeros(E, N, N, dtype=torch.float32, device=self.device)
-        self.shard.adjacency_expand(packed, dense)
+        self.shard.adjacency(packed, self.COMM_RANGE, dense)
         return self._squeeze(dense)
 
     def _clear_history(self):  # self.X = deque([]); self.A = deque([])  (MRS.py:185-186)
@@ -568,8 +570,10 @@ class MRS(_EnvBase):
         xr, ar = self._Xring, self._Apacked
         xslot = xr.next_slot()
         aslot = ar.next_slot() if want_A else 0
+        dr = self._Adense if want_A else None       # A_FORMAT = "dense": the float32 matrices come out of the same launch
+        dslot = dr.next_slot() if dr is not None else 0
         self.shard.step_ptr(actions, at, xr.ptr(xslot) if fused else 0, ar.ptr(aslot) if want_A else 0,
-                            float(self.COMM_RANGE))
+                            float(self.COMM_RANGE), dr.ptr(dslot) if dr is not None else 0)
         if not fused:
             self._obs.write_into(xr.buf[xslot])
         xr.committed()
@@ -577,7 +581,8 @@ class MRS(_EnvBase):
         Ak = None
         if want_A:
             ar.committed()
-            self._expand_newest_A()
+            if dr is not None:
+                dr.committed()
             Ak = self.get_Ak()
         mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
         if mode == "lazy" and (self._global_step & 255) == 255:   # _global_step: never zeroed by reset()

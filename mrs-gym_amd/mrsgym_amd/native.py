@@ -54,7 +54,7 @@ class MrsParams(C.Structure):
 
 class MrsBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pos", "quat", "vel", "angvel", "pid", "obs", "adj", "rpm", "status")]
+                ("pos", "quat", "vel", "angvel", "pid", "obs", "adj", "rpm", "status", "adj_dense")]
 
 
 _lib = None
@@ -101,7 +101,7 @@ def lib():
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
-        if L.mrs_abi_version() != 3:
+        if L.mrs_abi_version() != 4:
             raise MrsNativeError("libmrs_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -221,8 +221,9 @@ class SwarmShard:
         self.params = params
         _check(self.L.mrs_set_params(self.h, C.byref(params)), "mrs_set_params")
 
-    def _buffers(self, obs=None, adj=None):
+    def _buffers(self, obs=None, adj=None, adj_dense=None):
         b = MrsBuffers()
+        b.adj_dense = adj_dense.data_ptr() if adj_dense is not None else None
         b.pos, b.quat, b.vel, b.angvel = self.pos.data_ptr(), self.quat.data_ptr(), self.vel.data_ptr(), self.angvel.data_ptr()
         b.pid = self.pid.data_ptr()
         b.obs = obs.data_ptr() if obs is not None else None
@@ -280,8 +281,9 @@ class SwarmShard:
         b = self._buffers()
         _check(self.L.mrs_pid_reset(self.h, C.byref(b), _ptr(mask), _stream(self.device)), "mrs_pid_reset")
 
-    def step(self, actions, action_type, obs_out=None, adj_out=None, comm_range=float("nan")):
-        """One fused step.  actions: (E,N,adim) float32 device tensor (or None with action_type None)."""
+    def step(self, actions, action_type, obs_out=None, adj_out=None, comm_range=float("nan"), dense_out=None):
+        """One fused step.  actions: (E,N,adim) float32 device tensor (or None with action_type None).
+        dense_out (E,N,N) float32: the adjacency also as the matrices the reference returns (needs adj_out)."""
         at = action_type if isinstance(action_type, int) else ACT.get(action_type, -1)
         if actions is None:
             at = 0
@@ -290,7 +292,7 @@ class SwarmShard:
                 actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
             if actions.numel() != self.T * ACT_DIM[at]:
                 raise ValueError("actions has %d elements, expected (E,N,%d)" % (actions.numel(), ACT_DIM[at]))
-        b = self._buffers(obs_out, adj_out)
+        b = self._buffers(obs_out, adj_out, dense_out)
         self.version += 1
         cr = float(comm_range) if adj_out is not None else float("nan")
         rc = self.L.mrs_step(self.h, C.byref(b), _ptr(actions), at, self.obs_codes, self.n_obs if obs_out is not None else 0,
@@ -299,13 +301,14 @@ class SwarmShard:
             raise AttributeError("'Quadcopter' object has no attribute %r" % (action_type,))   # Environment.py:92
         _check(rc, "mrs_step")
 
-    def step_ptr(self, actions, at, obs_ptr, adj_ptr, comm_range):
+    def step_ptr(self, actions, at, obs_ptr, adj_ptr, comm_range, dense_ptr=0):
         """Per-step fast path for MRS.step: `actions` is a contiguous float32 device tensor (or None),
-        `at` the integer ACTION_TYPE, obs_ptr / adj_ptr raw device addresses (0 = skip).  The MrsBuffers
-        struct is persistent (the state tensors are never reallocated); only two fields change per step."""
+        `at` the integer ACTION_TYPE, obs_ptr / adj_ptr / dense_ptr raw device addresses (0 = skip).  The MrsBuffers
+        struct is persistent (the state tensors are never reallocated); only three fields change per step."""
         b = self._pb
         b.obs = obs_ptr or None
         b.adj = adj_ptr or None
+        b.adj_dense = dense_ptr or None
         self.version += 1
         rc = self.L.mrs_step(self.h, self._pb_ref, actions.data_ptr() if actions is not None else None, at, self.obs_codes,
                              self.n_obs if obs_ptr else 0, comm_range if adj_ptr else _NAN,
@@ -343,6 +346,7 @@ class SwarmShard:
         b = self._pb
         b.obs = obs_ptr or None
         b.adj = adj_ptr or None
+        b.adj_dense = None
         self.version += 1
         rc = self.L.mrs_step_n(self.h, self._pb_ref, actions.data_ptr() if actions is not None else None, at, n, act_stride, self.obs_codes,
                                self.n_obs if obs_ptr else 0, comm_range if adj_ptr else _NAN, obs_stride, adj_stride,
@@ -359,8 +363,8 @@ class SwarmShard:
             codes, n = (C.c_int32 * max(1, len(lst)))(*lst), len(lst)
         _check(self.L.mrs_observe(self.h, C.byref(b), codes, n, _stream(self.device)), "mrs_observe")
 
-    def adjacency(self, adj_out, comm_range):
-        b = self._buffers(None, adj_out)
+    def adjacency(self, adj_out, comm_range, dense_out=None):
+        b = self._buffers(None, adj_out, dense_out)
         _check(self.L.mrs_adjacency(self.h, C.byref(b), float(comm_range), _stream(self.device)), "mrs_adjacency")
 
     def adjacency_expand(self, packed, dense_out):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), "libmrs_hip.so does not export %s" % n
-    assert lib.mrs_abi_version() == 3
+    assert lib.mrs_abi_version() == 4
 
 
 def test_binding_covers_header():

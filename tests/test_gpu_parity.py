@@ -250,6 +250,38 @@ def test_adjacency_of_multi_wave_envs_bit_exact(N):
     assert np.array_equal(dense.cpu().numpy(), np.stack([oracle.adjacency(p32[e], 2.5) for e in range(E)]))
 
 
+@pytest.mark.parametrize("N", [64, 128, 192, 256, 12, 130])
+def test_dense_matrices_from_the_step_equal_the_expanded_rows(N):
+    """MrsBuffers.adj_dense: the float32 matrices the reference returns, written by the kernel that builds the rows (envs of
+    whole waves) or by the expand kernel behind it (N = 12, 130): either way exactly the expansion of the packed rows of the
+    same call -- after steps, through the standalone entry, for COMM_RANGE = inf, and with an env in contact range (N = 256:
+    the dense rows are the COMM_RANGE rows, not the contact-range rows of the flagged env's second pass)."""
+    import mrsgym_amd
+    E = 5
+    rng = np.random.default_rng(7 * N)
+    pos = rng.uniform(-2.0, 2.0, (E, N, 3)).astype(np.float32)
+    pos[..., 2] += 30.0
+    z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.set_state(pos=pos, ori=z, vel=z, angvel=z)
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    dense = torch.full((E, N, N), -7.0, device="cuda:0"); want = torch.zeros(E, N, N, device="cuda:0")
+    acts = ActionStream("set_speeds", E, N, pos, seed=5)
+    for t in range(4):
+        R = (2.5, float("inf"), 0.7, 2.5)[t]
+        dense.fill_(-7.0)
+        sh.step(torch.from_numpy(acts(t)).cuda(), "set_speeds", adj_out=adj, comm_range=R, dense_out=dense)
+        sh.adjacency_expand(adj, want)
+        assert torch.equal(dense, want), (t, R)
+        assert float(want.sum()) > 0
+    dense.fill_(-7.0)
+    sh.adjacency(adj, 1.5, dense)
+    sh.adjacency_expand(adj, want)
+    assert torch.equal(dense, want)
+    p32 = sh.view(sh.pos).cpu().numpy().astype(np.float32)
+    assert np.array_equal(want.cpu().numpy(), np.stack([oracle.adjacency(p32[e], 1.5) for e in range(E)]))
+
+
 def test_reference_trajectories_F6(golden_dir):
     """The reference's own MRS.step() trajectories (fake-bullet harness), teacher-forced on the GPU."""
     import glob
