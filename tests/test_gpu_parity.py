@@ -215,6 +215,38 @@ def test_adjacency_golden_bit_exact(golden_dir):
         assert np.array_equal(got.astype(np.uint8), want), Rk
 
 
+@pytest.mark.parametrize("N", [128, 256])
+def test_multi_wave_envs_in_larger_workgroups(N):
+    """MRS_STEP_BLOCK=512 puts two (N = 256) or four (N = 128) envs into one workgroup: the per-wave tiles and the travelling
+    sums of the downwash are the same code, the adjacency falls back to the all-pairs rows (adjacency_blocks is written for
+    256-thread workgroups).  Same arithmetic per agent: states and rows bitwise equal to the default 256-thread form."""
+    import mrsgym_amd
+    E = 5
+    pos, eul = grid_spawn(E, N, seed=N)
+    pos[..., 2] = 0.55 + 0.5 * (pos[..., 2] - 1.0)
+    z = np.zeros((E, N, 3), np.float32)
+    stream = ActionStream("set_target_vel", E, N, pos, seed=2)
+    table = [torch.from_numpy(stream(t)).cuda() for t in range(30)]
+    out = {}
+    old = os.environ.get("MRS_STEP_BLOCK")
+    try:
+        for blk in ("256", "512"):
+            os.environ["MRS_STEP_BLOCK"] = blk
+            sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+            sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+            obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+            for t in range(30):
+                sh.step(table[t], "set_target_vel", obs_out=obs, adj_out=adj, comm_range=2.0)
+            out[blk] = [getattr(sh, k).clone() for k in ("pos", "quat", "vel", "angvel")] + [obs.clone(), adj.clone()]
+    finally:
+        if old is None:
+            os.environ.pop("MRS_STEP_BLOCK", None)
+        else:
+            os.environ["MRS_STEP_BLOCK"] = old
+    for a, b in zip(out["256"], out["512"]):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 @pytest.mark.parametrize("N", [128, 192, 256])
 def test_adjacency_of_multi_wave_envs_bit_exact(N):
     """N = 128, 192, 256: an env is 2..4 waves and every unordered pair is tested once (adjacency_blocks: own block, the
@@ -525,6 +557,55 @@ def test_full_size_bench_workload_properties():
     d = np.linalg.norm(p64[:, :, None, :] - p64[:, None, :, :], axis=-1)
     clear = np.abs(d - R) > 1e-4
     assert np.array_equal(bits[clear], ((d <= R) & ~np.eye(N, dtype=bool)[None])[clear])
+
+
+def test_full_size_c4_workload_properties():
+    """BASELINE.json configs[3] at full size (N=256 x 1024 envs, set_control, adjacency on, 200 steps into ground contact):
+    an env is four waves, the pair loops run once per unordered pair across them.  Size-independent properties: (a) 1024
+    copies of one env stay bitwise identical (deterministic, no cross-env term, no dependence on where a workgroup runs);
+    (b) the first envs of the real workload follow the CPU oracle; (c) rows symmetric, zero diagonal, equal to a float64
+    recount away from the threshold; the dense matrices of the same launch are the expansion of the rows."""
+    import mrsgym_amd
+    E, N, R = 1024, 256, 5.0
+    pos, eul = grid_spawn(E, N)
+    z = np.zeros((E, N, 3), np.float32)
+    acts = ActionStream("set_control", E, N, pos, seed=1000)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    one = lambda x: np.broadcast_to(x[:1], x.shape).copy()
+    sh.set_state(pos=one(pos), ori=one(eul), vel=z, angvel=z)
+    obs = torch.zeros(E, N, sh.D, device="cuda:0"); adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    a0 = [torch.from_numpy(one(acts(50 * k))).cuda() for k in range(4)]
+    for t in range(200):
+        sh.step(a0[t // 50], "set_control", obs_out=obs, adj_out=adj, comm_range=R)
+    for name in ("pos", "quat", "vel", "angvel"):
+        v = getattr(sh, name); v = v.view(v.shape[0], E, N)
+        assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(v[:, :1]).expand_as(v)), name
+    assert torch.equal(obs, obs[:1].expand_as(obs)) and torch.equal(adj, adj[:1].expand_as(adj))
+    assert float(sh.pos[2].min()) < 0.6
+    # the real workload
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z); sh.pid_reset()
+    n_or = 2
+    sw = oracle.OracleSwarm(n_or, N, nthreads=8)
+    sw.set_state(pos=pos[:n_or].astype(np.float64), euler=eul[:n_or], vel=z[:n_or].astype(np.float64), angvel=z[:n_or].astype(np.float64))
+    dense = torch.zeros(E, N, N, device="cuda:0")
+    for t in range(60):
+        a = acts(t)
+        sh.step(torch.from_numpy(a).cuda(), "set_control", obs_out=obs, adj_out=adj, comm_range=R, dense_out=dense if t == 59 else None)
+        sw.step(a[:n_or], "set_control")
+    g = _gpu_state(sh)
+    assert np.abs(g["pos"][:n_or] - sw.pos).max() < 2e-5 and np.abs(g["vel"][:n_or] - sw.vel).max() < 2e-5
+    assert float(((sh.quat ** 2).sum(0) - 1).abs().max()) < 1e-12
+    want = torch.zeros(E, N, N, device="cuda:0")
+    sh.adjacency_expand(adj, want)
+    assert torch.equal(dense, want)
+    bits = want[:64].cpu().numpy().astype(bool)                             # (E',i,j): the first 64 envs on the host
+    assert not bits[:, np.arange(N), np.arange(N)].any() and np.array_equal(bits, bits.transpose(0, 2, 1))
+    assert bool((want == want.transpose(1, 2)).all())                       # all of them on the device
+    p64 = sh.view(sh.pos)[:64].cpu().numpy()
+    d = np.linalg.norm(p64[:, :, None, :] - p64[:, None, :, :], axis=-1)
+    clear = np.abs(d - R) > 1e-4
+    assert np.array_equal(bits[clear], ((d <= R) & ~np.eye(N, dtype=bool)[None])[clear])
+    assert np.array_equal(bits[:n_or], sw.adjacency(R).astype(bool))
 
 
 @pytest.mark.parametrize("N", [2, 63, 65, 128, 129, 192, 200, 256, 257, 1000])
