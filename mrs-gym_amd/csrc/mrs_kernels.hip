@@ -879,10 +879,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     // N = 64 (one env per wave): the three-array tile of the packed pair loop (tile64_write); any other N, and the
     // MRS_EXACT_F32 build's all-pairs loop: one float4 per agent
     const bool tile_soa = n64 && !MRS_EXACT_F32;
-    // an env that spans several waves (64 < N <= 256, fused kernel) runs the symmetric ring below on the same kind of
-    // tile: three arrays of 2N floats per env, every coordinate twice, so that neighbours k and k+1 of a lane are one
-    // ds_read2_b32 at an un-wrapped index (6N floats per env; epb * N <= BLOCK, and the tile region holds 8 * BLOCK)
-    // N = 128, 192, 256: one N = 64 tile per wave (= per 64-agent block of the env), see downwash_cross
+    // An env that spans several waves (64 < N <= 256, fused kernel):
+    //  - N = 128, 192, 256: one N = 64 tile per wave (= per 64-agent block of the env), see downwash_cross;
+    //  - any other N: the symmetric ring below on the same kind of tile for the whole env -- three arrays of 2N floats, every
+    //    coordinate twice, so that neighbours k and k+1 of a lane are one ds_read2_b32 at an un-wrapped index (6N floats per
+    //    env; epb * N <= BLOCK, and the tile region holds 8 * BLOCK).
     const bool multi = !MRS_EXACT_F32 && FUSED && !n64 && ACT != MRS_ACT_NONE && AN > 64;
     const bool blk = multi && (AN & 63) == 0;
     const bool ring = multi && !blk;
@@ -938,15 +939,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     int my_slot = -1;
     bool parked = false;
 #if !MRS_EXACT_F32
-    // ---- downwash, envs that span several waves (64 < N <= 256, fused kernel): the pair term is symmetric
-    // (see the N = 64 loop below), so lane i evaluates the pairs (i, i+k) at ring distance k = 1..(N-1)/2 once and
-    // hands the term to the lower quadcopter -- across waves through an LDS exchange buffer laid over the not
-    // yet used state stash: R distances per workgroup barrier, double-buffered, received terms added in distance
-    // order (deterministic).  Half the transcendental work of the all-pairs loop (N = 256 x 1024 envs: 83.4 -> 77.2 us).
-    // Every thread runs the loop: the barriers are workgroup-wide and the trip count depends on N only.
-    // (Round 3 experiment, removed: the handed-over terms ADDED into one LDS word per receiving agent -- 64-bit fixed point, so
-    // that the sum does not depend on the order of arrival -- instead of laid out per ring distance and summed after a
-    // barrier per eight distances: N = 256 x 1024 envs 66.9 against 61.8 us per step, N = 128: 40.8 against 38.1.)
+    // ---- downwash, envs that span several waves (64 < N <= 256, fused kernel): the pair term is symmetric (see the N = 64
+    // loop below), so every unordered pair is evaluated once and the term handed to the lower quadcopter.
+    // Envs of whole waves (blk): per 64-agent block, the other agent's terms travelling in a register and ONE LDS word per
+    // lane handed to the other wave after the loop (downwash_cross; N = 256 x 1024 envs: 63.0 -> 54.9 us against the ring).
     if (blk && KO_KEEP(8)) {
         const int lane = tid & 63, wt = tid >> 6, nb = AN >> 6, b = i >> 6; // wt - b = the tile of the env's first block
         float *const my_tile = tile64(lds_tile, wt);
@@ -975,6 +971,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             if (!(nb & 1)) downwash_acc -= (double)my_tile[448 + lane];
         }
     }
+    // Any other N (ring): lane i evaluates the pairs (i, i+k) at ring distance k = 1..(N-1)/2 -- across waves through an LDS
+    // exchange buffer laid over the not yet used state stash: R distances per workgroup barrier, double-buffered, received
+    // terms added in distance order (deterministic).  Half the transcendental work of the all-pairs loop (N = 256 x 1024
+    // envs: 83.4 -> 77.2 us, round 2).  Every thread runs the loop: the barriers are workgroup-wide and the trip count depends
+    // on N only.  (Round 3 experiment, removed: the handed-over terms ADDED into one LDS word per receiving agent -- 64-bit
+    // fixed point, so that the sum does not depend on the order of arrival -- instead of laid out per ring distance and
+    // summed after a barrier per eight distances: N = 256 x 1024 envs 66.9 against 61.8 us per step, N = 128: 40.8 against 38.1.)
     constexpr int RING_R = 8;
     if (ring && KO_KEEP(8)) {
         float *xb = reinterpret_cast<float *>(ncontact + 2 + BLOCK); // [2][RING_R][BLOCK] floats inside sp[13][BLOCK] doubles
