@@ -147,10 +147,10 @@ def main():
     base = rank * E
     pos, eul = grid_spawn(E, N, env_base=base)
 
-    def make_env(a_format, lo=0, hi=None):
+    def make_env(a_format, lo=0, hi=None, atype=ATYPE):
         hi = E if hi is None else hi
         env = mrsgym_amd.make('mrs-v0', N_ENVS=hi - lo, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
-                              RETURN_A=True, ACTION_TYPE=ATYPE, HEADLESS=True, START_POS=torch.from_numpy(pos[lo:hi]),
+                              RETURN_A=True, ACTION_TYPE=atype, HEADLESS=True, START_POS=torch.from_numpy(pos[lo:hi]),
                               A_FORMAT=a_format, ENV_INDEX_BASE=base + lo, DEVICE=str(dev), CHECK_NAN="lazy",
                               HISTORY_SLOTS=int(os.environ.get("MRS_BENCH_HISTORY_SLOTS", "0")))
         env.reset(ori=torch.from_numpy(eul[lo:hi]))
@@ -166,7 +166,11 @@ def main():
     # durations 26.7 us before a 52 ms gap, 29 -> 33 us over the following 100 launches, back to 26.5 after ~1000), and
     # the first process on a fresh box more so.  The measured swarm is created BEFORE its warm-up for that reason.
     prewarm_s = float(os.environ.get("MRS_BENCH_PREWARM_S", "1.0"))
-    scratch = make_env("packed") if prewarm_s > 0 else None
+    # MRS_BENCH_PREWARM_ATYPE (tools/profile_round.sh: set_target_pos): the scratch swarm on another instantiation of the step
+    # kernel, so that under rocprofv3 the rows of `k_step<set_target_vel>` hold the measured swarm's launches only -- at the
+    # clock the sustained load settles at (per-wave shader-clock stamps: the same 37 k ticks per wave take 20.8 us 200 launches
+    # after an idle start and 17.9 us after 800; without the warm-up a profile of 1800 launches is a profile of that ramp)
+    scratch = make_env("packed", atype=os.environ.get("MRS_BENCH_PREWARM_ATYPE", ATYPE)) if prewarm_s > 0 else None
 
     def warm(seconds):
         if scratch is None:
@@ -181,8 +185,12 @@ def main():
     # EV_SPAN consecutive mrs_step launches, one span every EV_EVERY steps: on this stack a timing-event pair
     # costs the stream ~60 us (measured 137 us per step with a pair on every step against 76 us with none),
     # so the per-launch duration is sampled and the pair's cost amortised over the span.
+    # Round 3: the spans cover the whole timed region (50 of every 50 launches; the driver's 20-step form: one span of 20).  With
+    # spans of 10 the average came out 0.3 - 0.4 us ABOVE the wall-clock time per step of the same region -- the two records'
+    # own cost lands inside the span and was divided by 10 (tools/ev_span_test.sh: span 10: kernel 22.80 / step 22.46 us;
+    # span 25 ... 50: 22.29 / 22.28, 22.35 / 22.50) -- and a rocprofv3 kernel trace of the same run sat 0.9 us below it.
     EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
-    EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "10")), EV_EVERY, args.steps))
+    EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "50")), EV_EVERY, args.steps))
 
     def rollin(env):
         """ROLLIN untimed steps from the spawn state: the workload's steady state (a part of the swarm grounded).

@@ -8,7 +8,10 @@ root=$(pwd)
 out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-export MRS_BENCH_PREWARM_S=0   # profile the measured swarm only
+# the device warm-up runs on another instantiation of the step kernel (k_step<set_target_pos>): the rows of the measured
+# kernel hold the measured swarm's 700 roll-in + warm-up + timed launches only, at the clock a sustained load settles at
+# (without any warm-up the 1800 launches of a pass are a profile of the clock ramp after an idle start: 26 -> 21 us)
+export MRS_BENCH_PREWARM_S=0.5 MRS_BENCH_PREWARM_ATYPE=set_target_pos
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --steps 1000 --warmup 100 --no-cpu-baseline --no-dense-a --no-double-buffer > "$out/bench.json" 2> "$out/stats.err"
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -3,13 +3,14 @@ over the roll-in launches, the warm-up launches and the timed launches.
 
     python tools/trace_phases.py gpurun_out/prof_<tag>/stats/run_kernel_trace.csv [rollin=700] [warmup=100]
 
-(The --stats average mixes the three; the roll-in contains the swarm's touchdown wave.)"""
+(The --stats average mixes the three.)"""
 import csv, sys
 import numpy as np
 path = sys.argv[1]
 rollin = int(sys.argv[2]) if len(sys.argv) > 2 else 700
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].replace("void ", "").startswith("k_step<")]
+# k_step<4, ...> = set_target_vel, the measured swarm (the device warm-up of tools/profile_round.sh runs k_step<5, ...>)
+rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].replace("void ", "").startswith("k_step<4")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows])
 gap = np.array([(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(rows[:-1], rows[1:])])
