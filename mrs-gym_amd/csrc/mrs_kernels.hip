@@ -786,6 +786,10 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 // pose/outputs 0) keeps them abreast: 34.3 -> 31.8 us per step.  The contact solve, the one serial stretch that
 // three waves of its workgroup wait for, runs at 3.  Round 2: all four levels in use (pair loop 3, controller 2,
 // forces 1, outputs 0): 29.2 -> 28.7 us; equal priorities cost +2.5 us, leaders-first +2.8 us (tools/abl_run.sh).
+// End of round 3, envs of at most one wave (N <= 64): the ladder compressed to 3 / 3 / 2 / 1 / 1 (pair loop, controller, forces,
+// pose + stores, adjacency) -- 22.18 -> 21.68 us per step over twelve windows on one box, -0.1 ... -0.3 on three others
+// (tools/abl_run.sh; 3/3/1/0, 3/2/2/0, 3/2/1/1 no better than before, 3/3/3/0 +1.8, rising priorities +2.6).  Envs of several
+// waves keep 3 / 2 / 1 / 0 / 0: N = 256 x 1024 envs 45.8 against 47.2 us with the compressed ladder.
 #ifndef MRS_P_DW1
 #define MRS_P_DW1 3
 #define MRS_P_DW2 3
@@ -793,7 +797,13 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 #define MRS_P_FORCE 1 // rotor forces, aerodynamics, velocity integration (after the controller)
 #define MRS_P_TAIL 0
 #define MRS_P_ADJ 0
+#define MRS_P1_CTRL 3 // N <= 64
+#define MRS_P1_FORCE 2
+#define MRS_P1_TAIL 1
+#define MRS_P1_ADJ 1
 #endif
+// s_setprio takes an immediate: the choice between the two ladders is a (uniform) branch
+#define MRS_SETPRIO(one_wave, p1, pn) do { if (one_wave) __builtin_amdgcn_s_setprio(p1); else __builtin_amdgcn_s_setprio(pn); } while (0)
 #ifndef MRS_P_SOLVE
 #define MRS_P_SOLVE 3
 #endif
@@ -1084,7 +1094,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             }
         }
         TL(1); // pair loop
-        if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_CTRL);
+        if (FUSED) MRS_SETPRIO(AN <= 64, MRS_P1_CTRL, MRS_P_CTRL);
         if (ACT != MRS_ACT_NONE) {
             const MrsParams &P = A.P;
             double rpm[4];
@@ -1152,7 +1162,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #endif
             TL(2); // controller
 #ifdef MRS_P_FORCE
-            if (FUSED) __builtin_amdgcn_s_setprio(MRS_P_FORCE);
+            if (FUSED) MRS_SETPRIO(AN <= 64, MRS_P1_FORCE, MRS_P_FORCE);
 #endif
             // ---- Quadcopter.set_speeds (Quadcopter.py:38-45): rotor thrusts + yaw reaction torque.
             // With ACTION_TYPE=set_speeds the reference's arithmetic is float32 (float32 action tensor).
@@ -1376,7 +1386,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // between the two barriers, under the solver wave's serial chain, and the listed ones behind it.  25.9 against 23.4 us
         // per step: two exec-masked passes over the 13 state stores write partial cache lines instead of whole ones.)
         TL(6); // barrier 2
-        __builtin_amdgcn_s_setprio(MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
+        MRS_SETPRIO(AN <= 64, MRS_P1_TAIL, MRS_P_TAIL); // last phase, lowest priority: see MRS_P_* above
         reload();
         // (the mirror image of MRS_LATE_LOADS -- the 13 state stores spread over the passes of the adjacency pair loop
         // instead of one burst ahead of it -- was measured: no gain, 27.0 against 27.0 us per step)
@@ -1384,7 +1394,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         const float fpx = (float)p[0], fpy = (float)p[1], fpz = (float)p[2];
         // ---- newest observation slice + adjacency rows of the post-step state (MRS.py:255-257)
         TL(7); // pose + store
-        if (MRS_P_ADJ != MRS_P_TAIL) __builtin_amdgcn_s_setprio(MRS_P_ADJ);
+        if (MRS_P_ADJ != MRS_P_TAIL || MRS_P1_ADJ != MRS_P1_TAIL) MRS_SETPRIO(AN <= 64, MRS_P1_ADJ, MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
         // (Round 3 experiment, removed: the N = 64 adjacency pass taken out of this tail and run between the two barriers of the
         // hand-off on predicted positions -- final for every lane that is not listed -- with the listed agents' rows and columns
