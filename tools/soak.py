@@ -22,7 +22,7 @@ def run(E, N):
     st = {k: sh.view(getattr(sh, k)).clone() for k in ("pos", "quat", "vel", "angvel")}
     return st, int(sh.status.max()), obs.clone(), adj.clone()
 
-for E, N in ((4096, 64), (1024, 12), (256, 130)):
+for E, N in ((4096, 64), (1024, 12), (256, 130), (1024, 256), (512, 192), (1024, 128)):   # the last three: envs of whole waves (block scheme)
     t0 = time.time()
     a, sa, oa, aa = run(E, N)
     b, sb, ob, ab = run(E, N)
