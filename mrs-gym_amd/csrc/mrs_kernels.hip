@@ -620,6 +620,15 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
                                                 uint64_t *row, float4 mine, int e)
 {
     const bool n64 = A.N == 64;
+    // A NaN (or infinite) position -- a diverged or mis-set body -- is adjacent to nobody: torch's `dist <= R` is False for a
+    // NaN distance (MRS.py:121).  The sign-bit verdicts below read the sign of d^2 - T', and a NaN carries a sign of its own
+    // through the arithmetic (x86 hands out negative ones, and the negate modifiers of the packed subtractions flip them), so no
+    // NaN enters the pair loops at all: such a coordinate is replaced by a finite one far outside every range and different
+    // for every agent of the env (1e18 m times one plus its index: two such agents are 1e18 m apart as well).
+    {
+        const float far = 1e18f * (float)(1 + i);
+        mine.x = fabsf(mine.x) <= 1e17f ? mine.x : far; mine.y = fabsf(mine.y) <= 1e17f ? mine.y : far; mine.z = fabsf(mine.z) <= 1e17f ? mine.z : far;
+    }
     if (BLOCK == 256 && A.N > 64 && (A.N & 63) == 0) { // 128, 192, 256
         adjacency_blocks<BLOCK>(A, thr_s, comm_inf, lds_tile, tid, el, i, live, row, mine, e);
         return;

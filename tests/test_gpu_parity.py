@@ -282,6 +282,35 @@ def test_adjacency_of_multi_wave_envs_bit_exact(N):
     assert np.array_equal(dense.cpu().numpy(), np.stack([oracle.adjacency(p32[e], 2.5) for e in range(E)]))
 
 
+@pytest.mark.parametrize("N", [64, 256, 130, 12])
+def test_nan_positions_are_adjacent_to_nobody(N):
+    """MRS.py:121: `dist <= COMM_RANGE` is False for a NaN distance.  The kernels take their verdicts from the sign bit of
+    d^2 - T', and a NaN keeps its sign through the arithmetic: a NEGATIVE NaN (what 0.0 / 0.0 gives on the host) must not
+    read as "within range".  One agent per env with negative-NaN coordinates (all three, or only z), one with a positive NaN."""
+    import mrsgym_amd
+    E = 3
+    rng = np.random.default_rng(N)
+    pos = rng.uniform(-1.0, 1.0, (E, N, 3)).astype(np.float32)
+    pos[..., 2] += 30.0
+    neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), np.float32)[0]
+    a, b, c = 1, N // 2, N - 1
+    pos[:, a, :] = neg_nan; pos[:, b, 2] = neg_nan; pos[:, c, 0] = np.float32("nan")
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    z = np.zeros((E, N, 3), np.float32)
+    sh.set_state(pos=pos, ori=z, vel=z, angvel=z)
+    assert np.signbit(sh.view(sh.pos)[0, a, 0].item())          # the state keeps the negative NaN
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    dense = torch.zeros(E, N, N, device="cuda:0")
+    for R in (5.0, float("inf")):
+        sh.adjacency(adj, R, dense)
+        A = dense.cpu().numpy()
+        want = np.stack([oracle.adjacency(pos[e], R) for e in range(E)])
+        if np.isfinite(R):
+            for k in (a, b, c):
+                assert not A[:, k, :].any() and not A[:, :, k].any(), (R, k)
+        assert np.array_equal(A, want), R
+
+
 @pytest.mark.parametrize("N", [64, 128, 192, 256, 12, 130])
 def test_dense_matrices_from_the_step_equal_the_expanded_rows(N):
     """MrsBuffers.adj_dense: the float32 matrices the reference returns, written by the kernel that builds the rows (envs of
