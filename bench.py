@@ -126,7 +126,10 @@ def main():
     ap.add_argument("--no-dense-a", action="store_true", help="skip the extra dense-adjacency leg (N=1)")
     ap.add_argument("--dense-a", action="store_true", help="materialise the float32 (E,K+1,N,N) adjacency the reference returns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-double-buffer", action="store_true", help="skip the two-half-swarms-on-two-streams leg (N=1)")
+    ap.add_argument("--double-buffer", action="store_true", help="also run the two-half-swarms-on-two-streams leg (N=1; opt-in: it "
+                    "no longer beats the one-launch step, DESIGN.md section 6)")
+    ap.add_argument("--no-double-buffer", action="store_true", help="(accepted, no effect: the leg is opt-in since round 4)")
+    ap.add_argument("--no-model-legs", action="store_true", help="skip the `literal` and `solver6` legs beside `value` (N=1)")
     args = ap.parse_args()
 
     import mrsgym_amd
@@ -147,12 +150,14 @@ def main():
     base = rank * E
     pos, eul = grid_spawn(E, N, env_base=base)
 
-    def make_env(a_format, lo=0, hi=None, atype=ATYPE):
+    def make_env(a_format, lo=0, hi=None, atype=ATYPE, **model):
+        """**model: the fidelity knobs of the product (SOLVER_ITERS, ROUND_EULER_READBACK, REST_SHORTCUT, QUAD_CONTACT); none =
+        the library's defaults, which is what `value` is measured with."""
         hi = E if hi is None else hi
         env = mrsgym_amd.make('mrs-v0', N_ENVS=hi - lo, N_AGENTS=N, state_fn=state_fn, K_HOPS=K_HOPS, COMM_RANGE=COMM_RANGE,
                               RETURN_A=True, ACTION_TYPE=atype, HEADLESS=True, START_POS=torch.from_numpy(pos[lo:hi]),
                               A_FORMAT=a_format, ENV_INDEX_BASE=base + lo, DEVICE=str(dev), CHECK_NAN="lazy",
-                              HISTORY_SLOTS=int(os.environ.get("MRS_BENCH_HISTORY_SLOTS", "0")))
+                              HISTORY_SLOTS=int(os.environ.get("MRS_BENCH_HISTORY_SLOTS", "0")), **model)
         env.reset(ori=torch.from_numpy(eul[lo:hi]))
         return env
 
@@ -262,7 +267,14 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, host_elapsed, kernel_ms
 
+    def model_of(e):
+        prm = e.sim.params
+        return {"solver_iters": int(prm.solver_iters), "round_euler_readback": int(prm.round_euler_readback), "pair_contact": int(prm.pair_contact),
+                "rest_shortcut": int(prm.rest_shortcut), "enable_contact": int(prm.enable_contact),
+                "contact_sweeps_dtype": "float32", "state_dtype": "float64"}
+
     env = make_env("dense" if args.dense_a else "packed")
+    model = model_of(env)
     assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
     # the torch kernels of rollin()'s grounded-share expression are loaded here, not at their first use between roll-in and
     # warm-up (a code-object load is ~55 ms of host time with the GPU idle: kernel trace, tools/trace_bench.sh)
@@ -289,7 +301,24 @@ def main():
                                 "what": "same K steps with info['A'] as the dense float32 (E,K+1,N,N) tensor the reference returns "
                                         "(516 B per agent-step algorithmic, SURVEY.md 8d) instead of bit-packed rows"}
             del denv
-        if not args.no_double_buffer and E % 2 == 0:
+        if not args.no_model_legs and not args.dense_a:
+            # The headline must not hang on the fidelity knobs: the same K steps with every knob at its literal
+            # setting, and with the sweep cap of round 3's headline, each with its own event-timed kernel duration.
+            for key, knobs, what in (
+                    ("literal", dict(SOLVER_ITERS=10, ROUND_EULER_READBACK=True, REST_SHORTCUT=False),
+                     "every fidelity knob at its literal setting: 10 contact sweeps, the controller's float32 rounding of the Euler "
+                     "read-back (Object.py:97 -> QuadControl.py:99), every grounded body through the sweeps (no at-rest shortcut)"),
+                    ("solver6", dict(SOLVER_ITERS=6),
+                     "library defaults except a cap of 6 contact sweeps (round 3's headline setting; accuracy: tests/golden/F6c)")):
+                lenv = make_env("packed", **knobs)
+                warm(min(prewarm_s, 0.3))
+                rollin(lenv)
+                l_elapsed, _, l_kernel_ms = timed_region(lenv, args.rollin, False)
+                l_ach = ALGO_BYTES_PER_AGENT_STEP * E * N / (l_kernel_ms * 1e-3) / 1e9
+                extra[key] = {"value": agent_steps / l_elapsed, "unit": "agent-steps/s", "ms_per_step": l_elapsed / args.steps * 1e3,
+                              "kernel_ms": l_kernel_ms, "roofline_frac": l_ach / HBM_PEAK_GBS, "model": model_of(lenv), "what": what}
+                del lenv
+        if args.double_buffer and E % 2 == 0:
             # BESIDE `value`, never instead of it: the same swarm as two half-swarms on two streams, each stepping on its own
             # (the EnvPool / Sample-Factory pattern: a closed loop may use it, the policy for half A runs while half B steps).
             # The two kernels overlap, half A's tail and hand-off bubbles under half B's forces phase and vice versa.
@@ -378,6 +407,8 @@ def main():
                                "K_HOPS=3, state_fn=cat(pos,vel), A %s%s" % (E, "dense fp32" if args.dense_a else "bit-packed",
                                                                              ", joint observation all-gathered every step" if world > 1 else ""),
                    "n_agents": N, "n_envs_per_gpu": E, "k_hops": K_HOPS, "comm_range": COMM_RANGE,
+                   # the product's fidelity knobs as `value` was measured (the library's defaults; `literal` / `solver6` beside it)
+                   "model": model,
                    "parallelism": "env-sharded x%d, RCCL all-gather of the newest observation slice per step" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,

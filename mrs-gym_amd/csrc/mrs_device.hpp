@@ -352,6 +352,10 @@ MRS_DEV float div_ctrl_dt(float x, float dt32, const Recips &K)
 {
     if (!K.ctrl_div_fast) return f32div(x, dt32);
     const float q0 = f32mul(x, K.inv_ctrl_dt32);
+    // the refinement is exact arithmetic on FINITE NORMAL quotients only: x = +-inf or an overflowing x r would give
+    // fma(-dt, inf, x) = NaN where the division gives +-inf (a diverged env carries inf in the reference and in the oracle),
+    // and a subnormal quotient is rounded twice -- both go through the division proper
+    if (!(__builtin_fabsf(q0) <= 3.0e38f) || !(__builtin_fabsf(q0) >= 1.2e-38f)) return f32div(x, dt32);
     return __builtin_fmaf(__builtin_fmaf(-dt32, q0, x), K.inv_ctrl_dt32, q0);
 }
 

@@ -499,6 +499,9 @@ template <int BLOCK>
 __device__ __forceinline__ void adj_blocks_pass(float4 *lds_tile, int tid, bool live, const BlockIds &B, float4 mine, float thr_s, bool rows, bool want_min,
                                                 int run, uint64_t word[4], float dm[3])
 {
+    // x3 = lds_tile + 2 * BLOCK is k_step's `nanflag[256]` region (dead by the tail: the NaN vote is read once, before the pair
+    // loop) and ends exactly where `ncontact` starts: 4 waves x 64 words.  Only true for 256-thread workgroups.
+    static_assert(BLOCK == 256, "adjacency_blocks: the third exchange array overlays nanflag[256] of a 256-thread workgroup");
     const int lane = tid & 63, wt = tid >> 6, nb = B.nb, b = B.b, o = B.o; // wt - b = the tile of the env's first block
     uint32_t *const my_x = reinterpret_cast<uint32_t *>(tile64(lds_tile, wt)); // exchange words 384 + lane, 448 + lane: the tile's spare quarter
     uint32_t *const x3 = reinterpret_cast<uint32_t *>(lds_tile + 2 * BLOCK);    // the third one: behind the tiles
@@ -629,9 +632,11 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
         const float far = 1e18f * (float)(1 + i);
         mine.x = fabsf(mine.x) <= 1e17f ? mine.x : far; mine.y = fabsf(mine.y) <= 1e17f ? mine.y : far; mine.z = fabsf(mine.z) <= 1e17f ? mine.z : far;
     }
-    if (BLOCK == 256 && A.N > 64 && (A.N & 63) == 0) { // 128, 192, 256
-        adjacency_blocks<BLOCK>(A, thr_s, comm_inf, lds_tile, tid, el, i, live, row, mine, e);
-        return;
+    if constexpr (BLOCK == 256) {
+        if (A.N > 64 && (A.N & 63) == 0) { // 128, 192, 256
+            adjacency_blocks<BLOCK>(A, thr_s, comm_inf, lds_tile, tid, el, i, live, row, mine, e);
+            return;
+        }
     }
     const bool want_hit = A.pair_flag != nullptr;
     int *const hit_flag = reinterpret_cast<int *>(lds_tile) + 3 * BLOCK; // generic N: one word per env slot, behind the three arrays
@@ -835,7 +840,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 {
     const int AN = A.N, AEPB = A.epb, AW = A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
-    int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK);
+    int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK); // [256] read once (the NaN vote below) and DEAD afterwards:
+                                                                  // adjacency_blocks reuses it in the tail as its third exchange array
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
@@ -1295,7 +1301,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (doit) {
         TL(3); // forces + velocity integration
         // near the ground; a body lying flat at rest is finished here, in its own lane (contact_at_rest)
-        const bool grounded = needs_contact(A.P.enable_contact, A.park_z, p[2]) && !(MRS_REST_SHORTCUT && contact_at_rest(A.P, A.rc, p[2], q, v, w));
+        const bool grounded = needs_contact(A.P.enable_contact, A.park_z, p[2]) && !(MRS_REST_SHORTCUT && A.P.rest_shortcut && contact_at_rest(A.P, A.rc, p[2], q, v, w));
         if (FUSED) {
             parked = grounded;
         } else if (grounded) {
@@ -1614,18 +1620,34 @@ struct SpawnArgs {
     int cand_rounds, resume;
 };
 
-// MRS.generate_start_pos (MRS.py:127-154) for the default spawn distribution (MRS.py:69-78):
-// one workgroup per env; positions and the collision graph live in LDS.
+// torch's float32 norm over the last axis of get_relative_position (MRS.py:135, :152): sqrt(fma(dz,dz,fma(dy,dy,dx*dx))), the
+// chain tests/golden/F3 pins for calc_A; the layouts of tests/golden/F5b are reproduced bit for bit only with it.
+__device__ __forceinline__ float spawn_dist(float4 a, float4 b)
+{
+    const float dx = f32sub(a.x, b.x), dy = f32sub(a.y, b.y), dz = f32sub(a.z, b.z);
+    return f32sqrt(f32fma(dz, dz, f32fma(dy, dy, f32mul(dx, dx))));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+// MRS.generate_start_pos (MRS.py:127-154) for the default spawn distribution (MRS.py:69-78) or caller-drawn candidates:
+// one workgroup per env, one lane per agent; the layout lives in LDS, every lane keeps its own collision count.
+// The greedy pick of MRS.py:140-144 -- torch.mode over the row indices of the remaining collisions = the agent with the most
+// of them, the LOWEST index among equals -- is a workgroup-wide maximum of (count << 12 | 4095 - index) per pick (wave
+// shuffles + one LDS word per wave), after which every lane that still collides with the pick drops one from its count:
+// "collisions[idx,:] = 0; collisions[:,idx] = 0".  (Round 3 ran the picks on ONE thread: 210 us per call at E = 4096, N = 12.)
 __global__ void k_spawn(const SpawnArgs S)
 {
-    extern __shared__ float4 sp[]; // N positions, then N ints (collision count), then N ints (resample flag)
-    int *cnt = reinterpret_cast<int *>(sp + S.N);
-    int *flag = cnt + S.N;
-    __shared__ int s_total;
+    extern __shared__ float4 sp[]; // N positions
+    __shared__ unsigned s_wmax[2][16];
     const int e = blockIdx.x;
     if (S.mask && !S.mask[e]) return;
     const uint64_t ge = (uint64_t)(S.env_base + e);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
     const bool live = tid < S.N;
     uint32_t draws = 0;
     auto sample = [&](int i) {
@@ -1644,61 +1666,50 @@ __global__ void k_spawn(const SpawnArgs S)
             if (S.resume) sp[tid] = make_float4((float)S.b.pos[(size_t)e * S.N + tid], (float)S.b.pos[S.T + (size_t)e * S.N + tid],
                                                 (float)S.b.pos[2 * S.T + (size_t)e * S.N + tid], 0.f);
             else { const float *c = S.cand + (((size_t)e * S.cand_rounds) * S.N + tid) * 3; sp[tid] = make_float4(c[0], c[1], c[2], 0.f); }
-            flag[tid] = 0;
         }
         cand_next = S.resume ? 0 : 1;
-    } else if (live) { sample(tid); flag[tid] = 0; }
+    } else if (live) sample(tid);
     draws += 3;
     __syncthreads();
     int round = 0;
-    bool need_more = false;
+    bool need_more = false, failed = false;
+    unsigned it = 0; // picks so far: the parity selects the exchange row, one barrier per pick
     for (;; ++round) {
-        if (live) { // codist < 2*AGENT_RADIUS (MRS.py:135-138)
-            int c = 0;
-            const float4 me = sp[tid];
-            for (int j = 0; j < S.N; ++j) {
-                const float4 pj = sp[j];
-                const float dx = me.x - pj.x, dy = me.y - pj.y, dz = me.z - pj.z;
-                c += (j != tid) && (sqrtf(dx * dx + dy * dy + dz * dz) < S.min_dist);
+        int c = 0; // codist < 2*AGENT_RADIUS (MRS.py:135-138): this agent's row of `collisions`
+        const float4 me = live ? sp[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+            for (int j = 0; j < S.N; ++j) c += (j != tid) && (spawn_dist(me, sp[j]) < S.min_dist);
+        if (!__syncthreads_or(c > 0)) break;                    // while torch.any(codist < 2 R), MRS.py:137
+        if (round >= S.max_rounds) { failed = true; break; }
+        if (S.cand && cand_next >= S.cand_rounds) { failed = need_more = true; break; } // out of samples: the caller draws more and resumes
+        bool flagged = false;
+        for (;; ++it) { // MRS.py:140-144
+            unsigned key = (live && !flagged && c > 0) ? (((unsigned)c << 12) | (unsigned)(4095 - tid)) : 0u;
+            key = wave_max_u32(key);
+            if (nw > 1) {
+                if ((tid & 63) == 0) s_wmax[it & 1][tid >> 6] = key;
+                __syncthreads();
+                key = 0u;
+                for (int k = 0; k < nw; ++k) key = max(key, s_wmax[it & 1][k]);
             }
-            cnt[tid] = c;
+            if (key == 0u) break;
+            const int best = 4095 - (int)(key & 4095u);
+            if (tid == best) { flagged = true; c = 0; }
+            else if (live && !flagged && c > 0 && spawn_dist(me, sp[best]) < S.min_dist) c--;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int j = 0; j < S.N; ++j) tot += cnt[j];
-            s_total = tot;
-            // greedy (MRS.py:140-144): repeatedly take the most-colliding agent, drop its row/column
-            while (tot > 0 && round < S.max_rounds) {
-                int best = 0;
-                for (int j = 1; j < S.N; ++j) if (cnt[j] > cnt[best]) best = j;
-                if (cnt[best] == 0) break;
-                flag[best] = 1;
-                const float4 pb = sp[best];
-                for (int j = 0; j < S.N; ++j) {
-                    if (j == best || flag[j]) continue;
-                    const float4 pj = sp[j];
-                    const float dx = pb.x - pj.x, dy = pb.y - pj.y, dz = pb.z - pj.z;
-                    if (sqrtf(dx * dx + dy * dy + dz * dz) < S.min_dist) { cnt[j]--; tot -= 2; }
-                }
-                cnt[best] = 0;
-            }
+        ++it;
+        __syncthreads(); // every lane is through its reads of the layout
+        if (flagged) { // MRS.py:145-151
+            if (S.cand) {
+                const float *cd = S.cand + (((size_t)e * S.cand_rounds + cand_next) * S.N + tid) * 3;
+                sp[tid] = make_float4(cd[0], cd[1], cd[2], 0.f);
+            } else sample(tid);
         }
-        __syncthreads();
-        if (s_total == 0 || round >= S.max_rounds) break;
-        if (S.cand) {
-            if (cand_next >= S.cand_rounds) { need_more = true; break; } // out of samples: the caller draws more and resumes
-            if (live && flag[tid]) {
-                const float *c = S.cand + (((size_t)e * S.cand_rounds + cand_next) * S.N + tid) * 3;
-                sp[tid] = make_float4(c[0], c[1], c[2], 0.f);
-                flag[tid] = 0;
-            }
-            cand_next++;
-        } else if (live && flag[tid]) { sample(tid); flag[tid] = 0; } // MRS.py:146-151
+        cand_next++;
         draws += 3;
         __syncthreads();
     }
-    if (tid == 0 && s_total != 0 && S.b.status) atomicOr(&S.b.status[e], need_more ? MRS_STATUS_SPAWN_MORE : MRS_STATUS_SPAWN_FAIL);
+    if (tid == 0 && failed && S.b.status) atomicOr(&S.b.status[e], need_more ? MRS_STATUS_SPAWN_MORE : MRS_STATUS_SPAWN_FAIL);
     if (live) {
         const size_t a = (size_t)e * S.N + tid, T = S.T;
         const float4 me = sp[tid];
@@ -1832,7 +1843,7 @@ extern "C" int mrs_params_default(MrsParams *p)
     p->inertia[2] = p->mass / 12.0 * (lx * lx + lx * lx);
     p->lin_damp = (double)0.04f; p->ang_damp = (double)0.04f; p->max_coord_vel = 100.0; p->use_gyro = 1;
     p->ground_z = 0.5; p->friction = 1.5 * 0.5; p->erp = 0.2; p->contact_threshold = 0.02; // plane.urdf:5,24
-    p->solver_iters = 6; p->enable_contact = 1; p->pair_contact = 1;
+    p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1; p->rest_shortcut = 1;
     return 0;
 }
 
@@ -1972,8 +1983,12 @@ extern "C" void mrs_destroy(MrsHandle *h)
 static float d2_threshold(double comm_range)
 {
     // largest float t with sqrtf(t) <= (float)comm_range, so that "sqrt(d2) <= R" == "d2 <= t" exactly
-    const float r = (float)comm_range;
+    float r = (float)comm_range;
     if (!(r >= 0.f)) return -1.f;
+    // adjacency_phase moves non-finite (diverged) positions to finite ones >= 1e18 m away so that no NaN enters the sign-bit
+    // verdicts; a finite range at that scale would reach them (T' = inf, inf - inf = NaN).  Ranges above 1e17 m count as
+    // 1e17 m: positions beyond 1e17 m are treated as diverged anyway (same function), and a NaN agent stays adjacent to nobody.
+    if (r > 1e17f) r = 1e17f;
     float t = r * r;
     while (sqrtf(nextafterf(t, INFINITY)) <= r) t = nextafterf(t, INFINITY);
     while (t > 0.f && sqrtf(t) > r) t = nextafterf(t, -INFINITY);
@@ -2301,7 +2316,7 @@ extern "C" int mrs_spawn(MrsHandle *h, const MrsBuffers *b, uint64_t seed, int64
     S.max_rounds = max_rounds; S.min_dist = (float)(2 * agent_radius); S.T = (size_t)h->E * h->N;
     for (int k = 0; k < 3; ++k) { S.ori_lo[k] = ori_lo[k]; S.ori_hi[k] = ori_hi[k]; }
     const int block = ((h->N + 63) / 64) * 64;
-    const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
+    const size_t lds = (size_t)h->N * sizeof(float4);
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_spawn") : hipfail(e, "mrs_spawn launch");
@@ -2318,7 +2333,7 @@ extern "C" int mrs_spawn_from(MrsHandle *h, const MrsBuffers *b, const float *ca
     S.b = *b; S.mask = env_mask; S.E = h->E; S.N = h->N; S.max_rounds = 1 << 30; S.min_dist = (float)(2 * agent_radius);
     S.T = (size_t)h->E * h->N; S.cand = candidates; S.cand_rounds = n_rounds; S.resume = resume;
     const int block = ((h->N + 63) / 64) * 64;
-    const size_t lds = (size_t)h->N * (sizeof(float4) + 2 * sizeof(int));
+    const size_t lds = (size_t)h->N * sizeof(float4);
     hipLaunchKernelGGL(k_spawn, dim3(h->E), dim3(block), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? pairs_unknown(h, env_mask, (hipStream_t)stream, "mrs_spawn_from") : hipfail(e, "mrs_spawn_from launch");

@@ -78,6 +78,8 @@ class MRS(_EnvBase):
         self.CHECK_NAN = None         # "sync" | "lazy" | "off"; None = sync for N_ENVS==1 else lazy
         self.ROUND_EULER_READBACK = False   # True: the controller's literal float32 rounding of the Euler angles (include/mrs_hip.h)
         self.QUAD_CONTACT = True      # quad-quad contact (sphere model, MrsParams.pair_contact)
+        self.SOLVER_ITERS = None      # cap of the ground-contact sweeps per body and step (None = the library's default, 10)
+        self.REST_SHORTCUT = True     # bodies lying flat at rest finished in their own lane (MrsParams.rest_shortcut)
         self.HISTORY_SLOTS = 0        # ring length; 0 = 16*(K_HOPS+1)
         self.COPY_OUTPUTS = None      # None = clone returned stacks iff N_ENVS == 1 (reference returns fresh tensors)
         self.AUTO_RESET = False       # vectorised loops: envs whose `done` is set are reset inside step() (reset_envs)
@@ -106,6 +108,11 @@ class MRS(_EnvBase):
         params.gravity, params.dt = float(self.GRAVITY), float(self.DT)
         params.round_euler_readback = int(bool(self.ROUND_EULER_READBACK))
         params.pair_contact = int(bool(self.QUAD_CONTACT))
+        params.rest_shortcut = int(bool(self.REST_SHORTCUT))
+        if self.SOLVER_ITERS is not None:
+            if int(self.SOLVER_ITERS) < 1:
+                raise ValueError("SOLVER_ITERS must be >= 1")
+            params.solver_iters = int(self.SOLVER_ITERS)
         self.sim = types.SimpleNamespace(DT=float(self.DT), GRAVITY=float(self.GRAVITY), REAL_TIME=bool(self.REAL_TIME),
                                          HEADLESS=bool(self.HEADLESS), id=0, params=params)
         self.shard = native.SwarmShard(self.N_ENVS, self.N_AGENTS, self.device, params=params)

@@ -48,7 +48,7 @@ class MrsParams(C.Structure):
         ("use_gyro", C.c_int32), ("enable_contact", C.c_int32),
         ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("contact_threshold", C.c_double),
         ("solver_iters", C.c_int32), ("round_euler_readback", C.c_int32),
-        ("pair_contact", C.c_int32), ("reserved1", C.c_int32),
+        ("pair_contact", C.c_int32), ("rest_shortcut", C.c_int32),
     ]
 
 
@@ -101,7 +101,7 @@ def lib():
         for n in EXPORTS:
             if n not in ("mrs_last_error", "mrs_destroy"):
                 getattr(L, n).restype = C.c_int
-        if L.mrs_abi_version() != 4:
+        if L.mrs_abi_version() != 5:
             raise MrsNativeError("libmrs_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -241,6 +241,31 @@ class SwarmShard:
             t = t.reshape(shape[1:]).unsqueeze(0).expand(shape)     # one (N,k) value shared by every env
         return t.reshape(shape).contiguous()
 
+    def _out(self, t, name, shape, dtype):
+        """An output tensor of a tensor-taking method: the kernels write `shape` elements of `dtype` through its
+        data_ptr(), so anything smaller, of another type, on another device or strided is refused HERE -- a mis-sized
+        buffer is otherwise a GPU memory fault, not an exception (round 3: a (E,N,1) adjacency buffer handed to an
+        N = 256 swarm, four words per row, took the process down with "Write access to a read-only page").  The
+        `*_ptr` fast paths of MRS.step skip this: their slots are allocated by HistoryRing with these shapes."""
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            raise ValueError("%s must be a torch tensor, got %s" % (name, type(t).__name__))
+        n = 1
+        for k in shape:
+            n *= int(k)
+        if t.device != self.device:
+            raise ValueError("%s is on %s, the shard is on %s" % (name, t.device, self.device))
+        if t.dtype != dtype:
+            raise ValueError("%s has dtype %s, expected %s" % (name, t.dtype, dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+        if t.numel() < n:
+            raise ValueError("%s has %d elements, the kernel writes %s = %d" % (name, t.numel(), "x".join(str(int(k)) for k in shape), n))
+        if t.data_ptr() % t.element_size():
+            raise ValueError("%s must be aligned to its element size" % name)
+        return t
+
     # ------------------------------------------------------------------ C-ABI calls
     def set_state(self, pos=None, ori=None, vel=None, angvel=None, env_mask=None):
         """Environment.set_state semantics: None keeps the current value (MRS.set)."""
@@ -292,6 +317,11 @@ class SwarmShard:
                 actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
             if actions.numel() != self.T * ACT_DIM[at]:
                 raise ValueError("actions has %d elements, expected (E,N,%d)" % (actions.numel(), ACT_DIM[at]))
+        self._out(obs_out, "obs_out", (self.E, self.N, self.D), torch.float32)
+        self._out(adj_out, "adj_out", (self.E, self.N, self.W), torch.int64)
+        self._out(dense_out, "dense_out", (self.E, self.N, self.N), torch.float32)
+        if dense_out is not None and adj_out is None:
+            raise ValueError("dense_out needs adj_out (the packed rows) as well")
         b = self._buffers(obs_out, adj_out, dense_out)
         self.version += 1
         cr = float(comm_range) if adj_out is not None else float("nan")
@@ -332,6 +362,10 @@ class SwarmShard:
                 stride = per
             elif actions.numel() != per:
                 raise ValueError("actions has %d elements, expected (E,N,%d) or (%d,E,N,%d)" % (actions.numel(), ACT_DIM[at], S, ACT_DIM[at]))
+        if S < 1:
+            raise ValueError("n_substeps must be >= 1")
+        self._out(obs_out, "obs_out", (S, self.E, self.N, self.D), torch.float32)
+        self._out(adj_out, "adj_out", (S, self.E, self.N, self.W), torch.int64)
         b = self._buffers(obs_out, adj_out)
         self.version += 1
         cr = float(comm_range) if adj_out is not None else float("nan")
@@ -356,19 +390,31 @@ class SwarmShard:
 
     def observe(self, obs_out, fields=None):
         """Newest observation slice of the current state; `fields` overrides the shard's fused spec for this call only."""
-        b = self._buffers(obs_out, None)
-        codes, n = self.obs_codes, self.n_obs
+        codes, n, D = self.obs_codes, self.n_obs, self.D
         if fields is not None:
             lst = [OBS[f] if isinstance(f, str) else int(f) for f in fields]
-            codes, n = (C.c_int32 * max(1, len(lst)))(*lst), len(lst)
+            codes, n, D = (C.c_int32 * max(1, len(lst)))(*lst), len(lst), sum(OBS_WIDTH[c] for c in lst)
+        if obs_out is None:
+            raise ValueError("obs_out is required")
+        self._out(obs_out, "obs_out", (self.E, self.N, D), torch.float32)
+        b = self._buffers(obs_out, None)
         _check(self.L.mrs_observe(self.h, C.byref(b), codes, n, _stream(self.device)), "mrs_observe")
 
     def adjacency(self, adj_out, comm_range, dense_out=None):
+        if adj_out is None:
+            raise ValueError("adj_out is required")
+        self._out(adj_out, "adj_out", (self.E, self.N, self.W), torch.int64)
+        self._out(dense_out, "dense_out", (self.E, self.N, self.N), torch.float32)
         b = self._buffers(None, adj_out, dense_out)
         _check(self.L.mrs_adjacency(self.h, C.byref(b), float(comm_range), _stream(self.device)), "mrs_adjacency")
 
     def adjacency_expand(self, packed, dense_out):
         n = packed.numel() // (self.N * self.W)
+        if packed.device != self.device or packed.dtype != torch.int64 or not packed.is_contiguous() or n * self.N * self.W != packed.numel():
+            raise ValueError("packed must be a contiguous int64 tensor (M, N=%d, W=%d) on %s" % (self.N, self.W, self.device))
+        self._out(dense_out, "dense_out", (n, self.N, self.N), torch.float32)
+        if dense_out is None:
+            raise ValueError("dense_out is required")
         _check(self.L.mrs_adjacency_expand(self.h, _ptr(packed), _ptr(dense_out), n, _stream(self.device)),
                "mrs_adjacency_expand")
 

@@ -106,6 +106,8 @@ def lib():
         _lib.orc_raycast.argtypes = [PP, C.c_int, dp, dp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, ip, fp, fp, fp]
         _lib.orc_closest.argtypes = [PP, C.c_int, dp, dp, C.c_int, dp, dp, dp]
         _lib.orc_proximity.argtypes = [PP, C.c_int, dp, dp, dp]
+        _lib.orc_spawn_from.argtypes = [C.c_int, C.c_int, fp, C.c_double, fp]
+        _lib.orc_spawn_from.restype = C.c_int
     return _lib
 
 
@@ -269,6 +271,15 @@ def proximity(pos, quat, params=None):
     D = np.zeros((N, N + 1))
     lib().orc_proximity(C.byref(p), N, _d(pos), _d(quat), _d(D))
     return D
+
+
+def spawn_from(cand, agent_radius=0.3):
+    """MRS.generate_start_pos on candidate rounds cand (R,N,3) float32 -> (final (N,3) float32, rounds consumed or -1)."""
+    c = f32(cand)
+    R, N = c.shape[0], c.shape[1]
+    pos = np.zeros((N, 3), np.float32)
+    used = lib().orc_spawn_from(N, R, _f(c), float(agent_radius), _f(pos))
+    return pos, used
 
 
 def integrate(params, pos, quat, vel, angvel, force_body, torque_body):

@@ -12,6 +12,7 @@
 #include "mrs_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -56,7 +57,7 @@ void orc_params_default(OrcParams *p)
     /* plane.urdf:24 box 30 30 1 centred at the origin, placed at pos 0 (EnvCreator.py:11) */
     p->ground_z = 0.5;
     p->friction = 1.5 * 0.5; /* plane.urdf:5 lateral 1.5 x default link friction 0.5 */
-    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 6; p->enable_contact = 1; p->pair_contact = 1;
+    p->erp = 0.2; p->contact_threshold = 0.02; p->solver_iters = 10; p->enable_contact = 1; p->pair_contact = 1;
 }
 
 void orc_derived(const OrcParams *p, double out[7])
@@ -766,6 +767,55 @@ static void pair_contact(const OrcParams *p, int N, float (*opos)[3], double *ve
     }
     for (int i = 0; i < N; ++i)
         for (int k = 0; k < 3; ++k) vel[3 * i + k] += (double)dv[i][k];
+}
+
+
+/* ------------------------------------------------------------------- spawn */
+
+/* MRS.generate_start_pos (MRS.py:127-154) as a function of the samples its START_POS hands out: cand[r][i] = what agent i
+ * receives if it is re-sampled in round r (round 0 = the first layout; per-agent draws :146-148 and joint draws :149-151
+ * look the same in this layout).  Pinned by tests/golden/F5b (the reference driven by a replay distribution).
+ * Returns the number of candidate rounds consumed (>= 1), or -1 if the layout still collides after n_rounds. */
+int orc_spawn_from(int N, int n_rounds, const float *cand, double agent_radius, float *pos)
+{
+    const float min_dist = (float)(2 * agent_radius); /* codist (float32) < 2*AGENT_RADIUS: the scalar joins in float32 */
+    unsigned char *col = (unsigned char *)malloc((size_t)N * N);
+    int *flag = (int *)malloc(sizeof(int) * (size_t)N);
+    memcpy(pos, cand, sizeof(float) * 3 * (size_t)N);
+    int used = 1;
+    for (;;) {
+        long total = 0;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                /* get_relative_position(...).norm(dim=2), :135: torch's float32 norm = sqrt(fma(dz,dz,fma(dy,dy,dx*dx))) */
+                const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+                const float d = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                col[(size_t)i * N + j] = (i != j) && (d < min_dist); /* diagonal = inf, :136 */
+                total += col[(size_t)i * N + j];
+            }
+        if (!total) break;                                   /* :137 */
+        if (used >= n_rounds) { used = -1; break; }
+        for (int i = 0; i < N; ++i) flag[i] = 0;
+        while (total) {                                      /* :140-144 */
+            /* torch.mode(torch.where(collisions)[0]): the row index that occurs most often, the smallest among equals */
+            int best = -1, bestc = 0;
+            for (int i = 0; i < N; ++i) {
+                int c = 0;
+                for (int j = 0; j < N; ++j) c += col[(size_t)i * N + j];
+                if (c > bestc) { bestc = c; best = i; }
+            }
+            flag[best] = 1;
+            for (int j = 0; j < N; ++j) {
+                total -= col[(size_t)best * N + j] + col[(size_t)j * N + best];
+                col[(size_t)best * N + j] = 0; col[(size_t)j * N + best] = 0;
+            }
+        }
+        for (int i = 0; i < N; ++i)                          /* :145-151 */
+            if (flag[i]) memcpy(pos + 3 * i, cand + ((size_t)used * N + i) * 3, sizeof(float) * 3);
+        used++;
+    }
+    free(col); free(flag);
+    return used;
 }
 
 /* -------------------------------------------------------------------- step */

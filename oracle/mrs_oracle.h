@@ -111,6 +111,10 @@ void orc_adjacency_batch(int E, int n, const float *pos, double comm_range, floa
  * K = 1): x_prev fp32 [E][N][D] = the PREVIOUS step's states, actions fp32 [E][N][3] */
 void orc_reynolds(int E, int n, int D, const float *x_prev, float *actions);
 
+/* MRS.generate_start_pos (MRS.py:127-154) on the sample stream laid out per round: cand fp32 [n_rounds][N][3], pos fp32 [N][3]
+ * out; returns the rounds consumed or -1 (layout still colliding after n_rounds).  Pinned by tests/golden/F5b. */
+int orc_spawn_from(int N, int n_rounds, const float *cand, double agent_radius, float *pos);
+
 /* One env step for E envs x N agents (MRS.py:240-257 without the callbacks).
  * Arrays are [E][N][k] row-major.  actions may be NULL (ORC_ACT_NONE).
  * speeds_out (optional) receives the rotor speeds used this step, [E][N][4] double;

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), "libmrs_hip.so does not export %s" % n
-    assert lib.mrs_abi_version() == 4
+    assert lib.mrs_abi_version() == 5
 
 
 def test_binding_covers_header():
@@ -36,7 +36,7 @@ def test_params_struct_layout_and_constants():
     # SURVEY.md 8a row P
     assert (p.mass, p.arm, p.kf, p.km) == (0.027, 0.0397, 3.16e-10, 7.94e-12)
     assert (p.gravity, p.dt, p.ctrl_gravity, p.ctrl_dt) == (9.81, 0.01, 9.81, 0.01)
-    assert p.ground_z == 0.5 and p.solver_iters == 6 and p.use_gyro == 1 and p.enable_contact == 1
+    assert p.ground_z == 0.5 and p.solver_iters == 10 and p.use_gyro == 1 and p.enable_contact == 1
     d = native.derived(p)
     assert d["HoverRPM"] == pytest.approx(14475.809152959684, rel=1e-14)
     assert d["GroundEffectHClip"] == pytest.approx(0.0377637, rel=1e-5)
@@ -44,7 +44,7 @@ def test_params_struct_layout_and_constants():
     import oracle
     o = oracle.default_params()
     for name, _ in native.MrsParams._fields_:
-        if name in ("round_euler_readback", "reserved1"):   # product-only switch (the oracle always rounds, like the reference)
+        if name in ("round_euler_readback", "rest_shortcut"):   # product-only switch (the oracle always rounds, like the reference)
             continue
         a, b = getattr(p, name), getattr(o, name)
         if hasattr(a, "__len__"):

@@ -22,3 +22,16 @@ def test_fma_division_by_ctrl_dt_is_correctly_rounded(dt):
         q1 = (q0.astype(np.float64) + (x64 - d64 * q0.astype(np.float64)) * r64).astype(np.float32)
     ok = np.isfinite(want) & (np.abs(want) > 1e-30)
     assert np.array_equal(q1[ok], want[ok])
+    # outside the refinement's domain the kernel takes the division proper: +-inf, quotients that overflow
+    # (near FLT_MAX) or are subnormal.  The guard is `1.2e-38 <= |q0| <= 3.0e38`; inside it the refinement must be exact
+    # -- checked above for |want| > 1e-30 -- and everything outside it must be caught.
+    big = np.array([np.inf, -np.inf, 3.4e38, -3.4e38, 3.3e36, 2.9e36, 1e-40, -1e-40, 1.3e-40, 0.0], np.float32)
+    with np.errstate(all="ignore"):
+        q0b = (big.astype(np.float64) * r64).astype(np.float32)
+        guarded = ~((np.abs(q0b) <= np.float32(3.0e38)) & (np.abs(q0b) >= np.float32(1.2e-38)))
+        wantb = (big.astype(np.float64) / d64).astype(np.float32)
+        q1b = (q0b.astype(np.float64) + (big.astype(np.float64) - d64 * q0b.astype(np.float64)) * r64).astype(np.float32)
+    assert guarded[0] and guarded[1] and guarded[-1]                        # inf, -inf, 0
+    assert np.isnan(q1b[0]) and np.isinf(wantb[0])                          # what the unguarded form would have returned
+    un = ~guarded
+    assert np.array_equal(q1b[un], wantb[un])

@@ -301,7 +301,7 @@ def test_nan_positions_are_adjacent_to_nobody(N):
     assert np.signbit(sh.view(sh.pos)[0, a, 0].item())          # the state keeps the negative NaN
     adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
     dense = torch.zeros(E, N, N, device="cuda:0")
-    for R in (5.0, float("inf")):
+    for R in (5.0, 1e19, float("inf")):       # 1e19: a finite range beyond the scale the diverged positions are moved to
         sh.adjacency(adj, R, dense)
         A = dense.cpu().numpy()
         want = np.stack([oracle.adjacency(pos[e], R) for e in range(E)])
@@ -404,6 +404,46 @@ def test_nan_action_skips_env_and_flags_it():
     np.testing.assert_array_equal(o[1, :, :3], after["pos"][1].astype(np.float32))
 
 
+def test_missized_output_buffers_raise_instead_of_faulting():
+    """Round 3's GPU memory fault (a diagnostic tool handed an N = 256 swarm, four words per adjacency row, a buffer of one
+    word per row): the tensor-taking methods of SwarmShard check numel / dtype / device / contiguity of every output."""
+    import mrsgym_amd
+    E, N = 2, 256
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    act = torch.zeros(E, N, 4, device="cuda:0")
+    good_obs = torch.zeros(E, N, sh.D, device="cuda:0")
+    good_adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")
+    assert sh.W == 4
+    with pytest.raises(ValueError, match="adj_out"):
+        sh.step(act, "set_control", obs_out=good_obs, adj_out=torch.zeros(E, N, 1, dtype=torch.int64, device="cuda:0"), comm_range=5.0)
+    with pytest.raises(ValueError, match="obs_out"):
+        sh.step(act, "set_control", obs_out=torch.zeros(E, N, 3, device="cuda:0"), adj_out=good_adj, comm_range=5.0)
+    with pytest.raises(ValueError, match="dtype"):
+        sh.step(act, "set_control", obs_out=good_obs.double(), adj_out=good_adj, comm_range=5.0)
+    with pytest.raises(ValueError, match="dtype"):
+        sh.step(act, "set_control", obs_out=good_obs, adj_out=good_adj.int(), comm_range=5.0)
+    with pytest.raises(ValueError, match="is on"):
+        sh.step(act, "set_control", obs_out=good_obs.cpu(), adj_out=good_adj, comm_range=5.0)
+    with pytest.raises(ValueError, match="contiguous"):
+        sh.step(act, "set_control", obs_out=torch.zeros(E, N, 2 * sh.D, device="cuda:0")[..., ::2], adj_out=good_adj, comm_range=5.0)
+    with pytest.raises(ValueError, match="dense_out"):
+        sh.step(act, "set_control", adj_out=good_adj, comm_range=5.0, dense_out=torch.zeros(E, N, 64, device="cuda:0"))
+    with pytest.raises(ValueError, match="dense_out"):
+        sh.adjacency(good_adj, 5.0, dense_out=torch.zeros(E, N, device="cuda:0"))
+    with pytest.raises(ValueError, match="adj_out"):
+        sh.adjacency(torch.zeros(E, N, dtype=torch.int64, device="cuda:0"), 5.0)
+    with pytest.raises(ValueError, match="obs_out"):
+        sh.observe(torch.zeros(E, N, 3, device="cuda:0"))
+    with pytest.raises(ValueError, match="dense_out"):
+        sh.adjacency_expand(good_adj, torch.zeros(E, N, N // 2, device="cuda:0"))
+    with pytest.raises(ValueError, match="obs_out"):
+        sh.step_n(act, "set_control", 3, obs_out=good_obs)
+    # the well-formed call still runs, and nothing above left the device in an error state
+    sh.step(act, "set_control", obs_out=good_obs, adj_out=good_adj, comm_range=5.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good_obs).all()
+
+
 def test_unknown_action_type_raises_attribute_error():
     sh, sw, _ = _mk(1, 3, None)
     with pytest.raises(AttributeError):                          # Environment.py:92 getattr
@@ -475,6 +515,42 @@ def test_spawn_properties():
     sh = mrsgym_amd.SwarmShard(2, 64, "cuda:0")
     sh.spawn(seed=1, agent_radius=0.3, max_rounds=50)
     assert (sh.status.cpu().numpy() & 2).all()
+
+
+def test_spawn_rejection_matches_reference_replay_F5b(golden_dir):
+    """Row R pinned: mrs_spawn_from on the candidate rounds the reference's generate_start_pos (MRS.py:127-154) consumed
+    under a replay distribution (tests/golden/F5b: per-agent and joint forms, N = 3, 12, 32, torch.mode ties planted; the
+    entries the reference never used are far-away sentinels) must end on the reference's layout BIT FOR BIT -- same picks
+    (most collisions, lowest index), same float32 distance (fma chain), same rounds."""
+    import mrsgym_amd
+    d = np.load(os.path.join(golden_dir, "F5b_spawn_replay.npz"))
+    names = sorted(k[:-5] for k in d.files if k.endswith("_cand"))
+    for N in (3, 12, 32):
+        group = [n for n in names if n.startswith("N%d_" % N)]
+        R = max(d[n + "_cand"].shape[0] for n in group)
+        E = len(group)
+        cand = np.zeros((E, R, N, 3), np.float32)
+        for e, n in enumerate(group):
+            c = d[n + "_cand"]
+            cand[e, :c.shape[0]] = c
+            # rounds past the reference's last one are never looked at: poison them
+            cand[e, c.shape[0]:] = np.nan
+        sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+        sh.spawn_from(torch.from_numpy(cand).cuda(), agent_radius=0.3)
+        got = sh.view(sh.pos).cpu().numpy()
+        assert int(sh.status.cpu().sum()) == 0
+        for e, n in enumerate(group):
+            assert np.array_equal(got[e].astype(np.float32), d[n + "_final"]) and np.array_equal(got[e], d[n + "_final"].astype(np.float64)), n
+        # one round short: flagged MRS_STATUS_SPAWN_MORE, and resuming with the missing round lands on the same layout
+        e_long = int(np.argmax([d[n + "_cand"].shape[0] for n in group]))
+        c = d[group[e_long] + "_cand"]
+        sh1 = mrsgym_amd.SwarmShard(1, N, "cuda:0")
+        sh1.spawn_from(torch.from_numpy(c[None, :-1]).cuda(), agent_radius=0.3)
+        assert int(sh1.status.cpu()[0]) & 4
+        sh1.status.zero_()
+        sh1.spawn_from(torch.from_numpy(c[None, -1:]).cuda(), agent_radius=0.3, resume=True)
+        assert int(sh1.status.cpu()[0]) == 0
+        assert np.array_equal(sh1.view(sh1.pos).cpu().numpy()[0], d[group[e_long] + "_final"].astype(np.float64))
 
 
 def test_env_sharding_is_bitwise():

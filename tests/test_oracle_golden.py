@@ -162,6 +162,58 @@ def test_F6_step_none_and_touchdown():
     assert sw.pos[0, 0, 2] < 0.56 and abs(sw.vel[0, 0, 2]) < 0.05      # came to rest on the ground top (z = 0.5)
 
 
+def _teacher_forced_errors(d, iters):
+    N = d["start"].shape[0]
+    sw = _swarm(d, N)
+    sw.p.solver_iters = iters
+    sw.p.pair_contact = 0           # the harness integrates every body on its own (oracle.integrate)
+    errs = []
+    for t in range(d["actions"].shape[0]):
+        sw.step(d["actions"][t], "set_speeds")
+        s = d["state"][t]
+        errs.append(np.abs(_state(sw) - s).max(1))
+        sw.pos[0], sw.quat[0], sw.vel[0], sw.angvel[0] = s[:, 0:3], s[:, 3:7], s[:, 7:10], s[:, 10:13]
+    return np.stack(errs)
+
+
+def test_F6c_default_sweep_cap_against_converged_contact():
+    """a fixture generated at a CONVERGED sweep count (50: bodies tumbling on the ground under rotor thrust, the
+    hard case of the sequential-impulse solve), and the oracle stepped at the library's DEFAULT cap teacher-forced along it.
+    Stated accuracy of the default (10 sweeps): 99 % of the body-steps within 2e-3, mean within 1.5e-4 of the converged solve
+    (m/s, rad/s; measured 9.3e-4 / 6.3e-5).  The bounds sit between 10 sweeps and 8 (4.0e-3 / 2.2e-4; 6 sweeps: 2.1e-2 /
+    8.2e-4; 12: 2.4e-4 / 2.1e-5; 20: 7.6e-7 / 3.7e-7), so lowering the default cap fails HERE instead of being absorbed by
+    regenerated goldens (round 3 went 10 -> 6 that way)."""
+    d = np.load(os.path.join(G, "F6c_tumbling_converged.npz"))
+    assert int(d["solver_iters"]) == 50
+    default = oracle.default_params().solver_iters
+    assert default >= 10
+    e = _teacher_forced_errors(d, default)
+    assert (d["state"][-1][:, 2] < 0.6).mean() > 0.7                       # they did end on the ground
+    assert np.quantile(e, 0.99) < 2e-3 and e.mean() < 1.5e-4, (np.quantile(e, 0.99), e.mean())
+    assert _teacher_forced_errors(d, 50).max() < 1e-6                       # the fixture's own count reproduces it (float32 ulps of the downwash term)
+    e8 = _teacher_forced_errors(d, 8)
+    assert np.quantile(e8, 0.99) > 2e-3 and e8.mean() > 1.5e-4                # the test does see a lower cap
+
+
+def test_F5b_spawn_rejection_replay(golden_dir):
+    """Row R: the reference's generate_start_pos (MRS.py:127-154) driven by a replay distribution -- per-agent and joint
+    forms, torch.mode ties planted -- against the oracle's restatement: final layout bit for bit, rounds consumed equal."""
+    d = np.load(os.path.join(golden_dir, "F5b_spawn_replay.npz"))
+    names = sorted(k[:-5] for k in d.files if k.endswith("_cand"))
+    assert len(names) == 48 and max(d[n + "_cand"].shape[0] for n in names) > 50
+    ties = 0
+    for n in names:
+        cand = d[n + "_cand"]
+        pos, used = oracle.spawn_from(cand)
+        assert used == cand.shape[0], n
+        assert np.array_equal(pos, d[n + "_final"]), n
+        ties += int(n.endswith("_0") or n.endswith("_1"))
+        # one round short: the layout still collides and the oracle says so
+        if cand.shape[0] > 1:
+            assert oracle.spawn_from(cand[:-1])[1] == -1, n
+    assert ties >= 12
+
+
 def test_F7_reynolds_expert(golden_dir):
     """oracle.reynolds vs the reference's Reynolds.forward_batch (examples/simulating_data/helper/Reynolds.py:80-110,
     K=1).  float32; the reference's torch reductions sum over neighbours in their own order, hence not bit-exact:

@@ -1,0 +1,137 @@
+"""Teacher-forced per-step parity on the literal BASELINE workloads (SURVEY.md section 8d inputs).
+
+The GPU swarm free-runs -- through touchdown, rest, tumbling on the ground and quad-quad contact, wherever the (chaotic)
+workload takes it -- and EVERY step the CPU oracle is re-seeded with the GPU's pre-step state (float64 state words and
+the controller memory) and takes the same one step: what is compared is one step of the kernel against one step of the
+restatement on identical inputs, at the state mix the benchmark times, not two diverging samples of a chaotic system.
+
+Test infrastructure (uses oracle/); shared by tests/test_gpu_teacher.py and tools/teacher_probe.py.
+"""
+import numpy as np
+
+import oracle
+from util_scenarios import ActionStream, grid_spawn
+
+# C2 set_speeds / RETURN_A=False, C3 set_target_vel / A / K=3, C4 set_control / A (N=256), C5 set_target_pos / A
+CONFIGS = {
+    "C2": dict(N=64, atype="set_speeds", comm_range=None),
+    "C3": dict(N=64, atype="set_target_vel", comm_range=5.0),
+    "C4": dict(N=256, atype="set_control", comm_range=5.0),
+    "C5": dict(N=64, atype="set_target_pos", comm_range=5.0),
+}
+PHASES = ("free", "rest", "listed", "pair")
+
+
+def pid_to_oracle(pid_records, out):
+    """MrsBuffers.pid (5, T, 4) float32 records (include/mrs_hip.h) -> the oracle's per-agent OrcPid array."""
+    r = pid_records
+    out["integral_pos_e"] = r[0][:, :3]
+    out["d_vel_e"] = r[1][:, :3]
+    out["integral_vel_e"] = np.stack([r[1][:, 3], r[2][:, 0], r[2][:, 1]], -1)
+    out["last_vel_e"] = np.stack([r[2][:, 2], r[2][:, 3], r[3][:, 0]], -1)
+    out["last_target_vel"] = r[3][:, 1:4]
+    out["integral_ori_e"] = r[4][:, :3]
+
+
+def classify(pre, P, N):
+    """Phase of every body from its PRE-step state (E,N,.): the branch the step takes for it.
+    pair: within quad-quad contact range of another agent (float32 positions, the kernel's and the oracle's test);
+    rest: near the ground, lying flat and still (the kernel's own-lane shortcut, contact_at_rest: |R20|,|R21|,|w|,|v_xy| < 1e-6);
+    listed: near the ground otherwise (the sequential-impulse sweeps); free: none of these."""
+    pos, quat, vel, ang = pre["pos"], pre["quat"], pre["vel"], pre["angvel"]
+    park_z = P.ground_z + np.sqrt(P.coll_radius ** 2 + P.coll_half_len ** 2) + P.contact_threshold
+    near = pos[..., 2] <= park_z
+    x, y, z, w = (quat[..., k] for k in range(4))
+    r20, r21 = 2 * (x * z - w * y), 2 * (y * z + w * x)
+    still = (np.abs(r20) < 1e-6) & (np.abs(r21) < 1e-6) & (np.abs(ang).max(-1) < 1e-6) & (np.abs(vel[..., :2]).max(-1) < 1e-6)
+    p32 = pos.astype(np.float32)
+    d = p32[:, :, None, :] - p32[:, None, :, :]
+    d2 = d[..., 2] * d[..., 2] + (d[..., 1] * d[..., 1] + d[..., 0] * d[..., 0])
+    rc = np.float32(2 * P.coll_radius) + np.float32(P.contact_threshold)
+    d2[:, np.arange(N), np.arange(N)] = np.inf
+    pair = (d2 <= rc * rc * np.float32(1.0001)).any(-1)
+    ph = np.zeros(pos.shape[:2], np.int8)          # free
+    ph[near & still] = 1
+    ph[near & ~still] = 2
+    ph[pair] = 3
+    return ph
+
+
+def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None):
+    """Returns dict: err[phase] = array of per-body per-step errors (max over the 13 state words, relative above
+    magnitude 1), visited counters, adjacency mismatches (must be 0)."""
+    c = CONFIGS[cfg]
+    N, atype, R = c["N"], c["atype"], c["comm_range"]
+    pos, eul = grid_spawn(E, N, seed=seed)                      # 1 m pitch, |yaw| <= pi/2: the literal spawn
+    z = np.zeros((E, N, 3), np.float32)
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    if params is not None:
+        sh.set_params(params)
+    P = sh.params
+    sh.set_state(pos=pos, ori=eul, vel=z, angvel=z)
+    sw = oracle.OracleSwarm(E, N, nthreads=nthreads)
+    for k in ("solver_iters", "enable_contact", "pair_contact"):
+        setattr(sw.p, k, int(getattr(P, k)))
+    acts = ActionStream(atype, E, N, pos, seed=1000 + seed)      # coherent=False: independent per-agent targets
+    obs = torch.zeros(E, N, sh.D, device="cuda:0")
+    adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0") if R is not None else None
+    dense = torch.zeros(E, N, N, device="cuda:0") if R is not None else None
+
+    def grab():
+        return {k: sh.view(getattr(sh, k)).cpu().numpy() for k in ("pos", "quat", "vel", "angvel")}
+
+    errs = {p: [] for p in PHASES}
+    worst = {p: (0.0, None) for p in PHASES}
+    visited = dict(touchdown=0, rest=0, tumbling=0, pair=0, listed=0, nnls=0)
+    adj_bad = 0
+    pre = grab()
+    was_near = np.zeros((E, N), bool)
+    for t in range(steps):
+        pid = sh.pid.cpu().numpy()
+        a = acts(t)
+        sh.step(torch.from_numpy(a).cuda(), atype, obs_out=obs, adj_out=adj, comm_range=R if R is not None else float("nan"))
+        post = grab()
+        # the oracle: this step from the GPU's pre-step state
+        sw.pos[...] = pre["pos"]; sw.quat[...] = pre["quat"]; sw.vel[...] = pre["vel"]; sw.angvel[...] = pre["angvel"]
+        pid_to_oracle(pid, sw.pid)
+        sw.step(a, atype)
+        ph = classify(pre, P, N)
+        e = np.zeros((E, N))
+        for k, ref in (("pos", sw.pos), ("quat", sw.quat), ("vel", sw.vel), ("angvel", sw.angvel)):
+            e = np.maximum(e, (np.abs(post[k] - ref) / np.maximum(1.0, np.abs(ref))).max(-1))
+        e = np.where(np.isfinite(e), e, np.inf)
+        for i, p in enumerate(PHASES):
+            m = ph == i
+            if m.any():
+                errs[p].append(e[m])
+                j = np.argmax(np.where(m, e, -1))
+                if e.flat[j] > worst[p][0]:
+                    worst[p] = (float(e.flat[j]), (t, int(j // N), int(j % N)))
+        near = ph >= 1
+        visited["touchdown"] += int(((ph == 2) & ~was_near & (pre["vel"][..., 2] < -0.1)).sum())
+        visited["rest"] += int((ph == 1).sum())
+        visited["listed"] += int((ph == 2).sum())
+        visited["tumbling"] += int(((ph == 2) & (np.abs(pre["angvel"]).max(-1) > 1.0)).sum())
+        visited["pair"] += int((ph == 3).sum())
+        was_near = near & (ph != 3) | (was_near & (ph == 3))
+        if R is not None and t % check_adj_every == 0:
+            sh.adjacency_expand(adj, dense)
+            p32 = np.ascontiguousarray(post["pos"].astype(np.float32))
+            want = np.stack([oracle.adjacency(p32[k], R) for k in range(E)])
+            adj_bad += int((dense.cpu().numpy() != want).sum())
+            o = obs.cpu().numpy()
+            adj_bad += int((o[..., :3] != p32).sum()) + int((o[..., 3:6] != post["vel"].astype(np.float32)).sum())
+        pre = post
+        if progress and t % 100 == 99:
+            progress(t + 1)
+    out = dict(cfg=cfg, E=E, N=N, steps=steps, visited=visited, adj_bad=adj_bad, worst=worst,
+               err={p: (np.concatenate(errs[p]) if errs[p] else np.zeros(0)) for p in PHASES},
+               grounded_share=float((pre["pos"][..., 2] < 0.6).mean()))
+    return out
+
+
+def quantiles(x):
+    if x.size == 0:
+        return None
+    q = np.quantile(x, [0.5, 0.99, 0.999])
+    return dict(n=int(x.size), q50=float(q[0]), q99=float(q[1]), q999=float(q[2]), max=float(x.max()))

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3t
-F="--no-cpu-baseline --no-dense-a --no-double-buffer"
+F="--no-cpu-baseline --no-dense-a --no-model-legs"
 for cfg in "10 50" "50 50" "25 50" "10 500" "40 50" "10 50"; do
   set -- $cfg
   MRS_BENCH_EVENT_SPAN=$1 MRS_BENCH_EVENT_EVERY=$2 python bench.py $F 2>/dev/null | python -c "

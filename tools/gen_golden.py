@@ -345,6 +345,107 @@ def gen_F5(mrsgym, out):
     np.savez_compressed(os.path.join(out, "F5_spawn.npz"), **data)
 
 
+class _Replay:
+    """A stand-in START_POS "distribution" (README.md:71-74) that hands back pre-drawn samples in order, so that the
+    reference's rejection loop becomes a deterministic function of a sample stream."""
+
+    def __init__(self, samples, events):
+        self.samples, self.k, self.events = samples, 0, events
+
+    def sample(self):
+        s = self.samples[self.k]
+        self.events.append(("sample", self.k))
+        self.k += 1
+        return s.clone()            # generate_start_pos writes into what it gets (MRS.py:148,151)
+
+
+def gen_F5b(mrsgym, out):
+    """Row R, deterministic: MRS.generate_start_pos (MRS.py:127-154) driven by a replay distribution, per-agent
+    ((3,) samples, :132-134, :146-148) and joint ((N,3) samples, :149-151) forms, incl. torch.mode ties (:141).
+
+    What is stored per case is the candidate tensor in the layout mrs_spawn_from takes -- cand[r][i] = the sample agent i
+    receives if it is re-sampled in round r (round 0 = the first layout) -- rebuilt from the order in which the reference
+    consumed the stream (its torch.mode picks and sample() calls are logged by pass-through wrappers; nothing of the
+    reference is modified); entries the reference never used are far-away sentinels, so an implementation that flags a
+    different agent ends somewhere else.  Expected: the final layout, bit for bit, and the rounds it took."""
+    import torch
+    rng = np.random.default_rng(505)
+    data = {}
+    real_mode = torch.mode
+    boxes = {3: (0.45, 0.45, (1.0, 1.5)), 12: (1.0, 1.0, (1.0, 2.2)), 32: (1.5, 1.5, (1.0, 3.0))}
+    names = []
+    try:
+        for N in (3, 12, 32):
+            bx, by, bz = boxes[N]
+            for form in ("agent", "joint"):
+                for case in range(8):
+                    def draw(shape):
+                        p = np.stack([rng.uniform(-bx, bx, shape), rng.uniform(-by, by, shape), rng.uniform(bz[0], bz[1], shape)], -1)
+                        return p.astype(np.float32)
+                    n_stream = 4000 if form == "agent" else 400
+                    stream = draw((n_stream,)) if form == "agent" else draw((n_stream, N))
+                    if case == 0:
+                        # planted ties: every agent collides with every other one (all counts equal) in the first layout
+                        if form == "agent":
+                            stream[1:N + 1] = stream[1] + rng.uniform(-0.05, 0.05, (N, 3)).astype(np.float32)
+                        else:
+                            stream[0] = stream[0, 0] + rng.uniform(-0.05, 0.05, (N, 3)).astype(np.float32)
+                    if case == 1 and N >= 4:
+                        # planted ties: disjoint colliding pairs (counts 1,1,1,1,...), the rest far apart
+                        base = np.stack([np.arange(N) * 2.0, np.zeros(N), np.full(N, 1.5)], -1).astype(np.float32)
+                        base[1] = base[0] + np.float32([0.3, 0, 0]); base[3] = base[2] + np.float32([0, 0.3, 0])
+                        if form == "agent":
+                            stream[1:N + 1] = base
+                        else:
+                            stream[0] = base
+                    events = []
+                    torch.mode = lambda *a, **k: (lambda r: (events.append(("mode", int(r[0]))), r)[1])(real_mode(*a, **k))
+                    m = _bare_mrs(mrsgym, N, 0, float("inf"))
+                    m.AGENT_RADIUS = 0.3
+                    m.START_POS = _Replay([torch.from_numpy(x.copy()) for x in stream], events)
+                    final = m.generate_start_pos().numpy().copy()
+                    torch.mode = real_mode
+                    # rebuild (rounds, N, 3) candidates from the event log
+                    sentinel = lambda r: np.stack([1e4 + 10.0 * np.arange(N), np.full(N, 1e4 + 10.0 * r), np.zeros(N)], -1).astype(np.float32)
+                    rounds = []
+                    if form == "agent":
+                        assert [e for e in events[:N + 1]] == [("sample", k) for k in range(N + 1)]
+                        rounds.append(stream[1:N + 1].copy())
+                        ev = events[N + 1:]
+                    else:
+                        assert events[0] == ("sample", 0)
+                        rounds.append(stream[0].copy())
+                        ev = events[1:]
+                    flagged = []
+                    i = 0
+                    while i < len(ev):
+                        picks = []
+                        while i < len(ev) and ev[i][0] == "mode":
+                            picks.append(ev[i][1]); i += 1
+                        c = sentinel(len(rounds))
+                        if form == "agent":
+                            for idx in picks:
+                                assert ev[i][0] == "sample"
+                                c[idx] = stream[ev[i][1]]; i += 1
+                        else:
+                            assert ev[i][0] == "sample"
+                            c[picks] = stream[ev[i][1]][picks]; i += 1
+                        rounds.append(c)
+                        f = np.full(N, -1, np.int32); f[:len(picks)] = picks
+                        flagged.append(f)
+                    key = "N%d_%s_%d" % (N, form, case)
+                    names.append(key)
+                    data[key + "_cand"] = np.stack(rounds)
+                    data[key + "_final"] = final
+                    data[key + "_flagged"] = np.stack(flagged) if flagged else np.zeros((0, N), np.int32)
+                    d = np.linalg.norm(final[:, None] - final[None], axis=-1) + np.eye(N) * 9
+                    assert d.min() >= 0.6 - 1e-6
+    finally:
+        torch.mode = real_mode
+    np.savez_compressed(os.path.join(out, "F5b_spawn_replay.npz"), **data)
+    return {k: int(data[k + "_cand"].shape[0]) for k in names}
+
+
 def gen_F6(out):
     """Full MRS.step() trajectories through the fake-bullet harness."""
     import torch
@@ -444,6 +545,36 @@ def gen_F6(out):
         states.append(np.stack([np.concatenate([fake.bodies[a.uid][k] for k in ("pos", "quat", "vel", "angvel")]) for a in env.env.agents]))
     np.savez_compressed(os.path.join(out, "F6_step_none_touchdown.npz"), start=start,
                         ori0=np.array([[0.2, -0.1, 0.3], [0, 0, 0], [0.5, 0.4, -1.0]], np.float32), state=np.stack(states))
+    env.close()
+    del env
+    import gc
+    gc.collect()        # MRS.__del__ -> close() -> p.resetSimulation: let the old env go BEFORE the next one loads its bodies
+    # Contact sweeps at a CONVERGED count: twelve quadcopters dropped tilted from just above the ground with rotor
+    # speeds of hover +-5 % -- they tumble on the ground under thrust, the hard case of the sequential-impulse solve -- through
+    # the same harness with solver_iters = 50 (pybullet's own default, BulletSim.py:34 sets none; the sweeps stop on
+    # convergence well before).  tests/test_oracle_golden.py steps the oracle at its DEFAULT cap teacher-forced along this
+    # trajectory: a lower default shows up there as a failing test, not as a regenerated fixture.
+    fake.__init__()
+    fake.params.solver_iters = 50
+    N, T = 12, 300
+    r2 = np.random.default_rng(66)
+    side = 4
+    grid = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:N] - (side - 1) / 2
+    start = np.concatenate([grid + r2.uniform(-.2, .2, (N, 2)), r2.uniform(0.56, 0.9, (N, 1))], 1).astype(np.float32)
+    ori0 = np.concatenate([r2.uniform(-.5, .5, (N, 2)), r2.uniform(-np.pi / 2, np.pi / 2, (N, 1))], 1).astype(np.float32)
+    env = mrsgym.MRS(state_fn=state_fn, N_AGENTS=N, K_HOPS=0, ACTION_TYPE="set_speeds", HEADLESS=True, START_POS=torch.tensor(start))
+    env.reset(ori=torch.tensor(ori0))
+    acts, states = [], []
+    for t in range(T):
+        a32 = torch.tensor(hover * (1 + 0.05 * r2.uniform(-1, 1, (N, 4))), dtype=torch.float32)
+        env.step(a32)
+        acts.append(a32.numpy().copy())
+        states.append(np.stack([np.concatenate([fake.bodies[a.uid][k] for k in ("pos", "quat", "vel", "angvel")]) for a in env.env.agents]))
+    np.savez_compressed(os.path.join(out, "F6c_tumbling_converged.npz"), start=start, ori0=ori0, actions=np.stack(acts),
+                        state=np.stack(states), solver_iters=50)
+    print("  F6c tumbling, converged sweeps: final z", np.stack(states)[-1][:, 2].round(3)[:6])
+    env.close()
+    fake.__init__()
     return cases
 
 
@@ -519,21 +650,30 @@ def main():
         import_reference(FakeBullet())
         print("F8", gen_F8(args.out))
         return
+    if args.only == "F6":
+        print("F6", gen_F6(args.out))
+        return
+    if args.only == "F5b":
+        print("F5b rounds", gen_F5b(import_reference(FakeBullet()), args.out))
+        return
     mrsgym = import_reference(FakeBullet())
     print("F1 anchor", gen_F1(mrsgym, args.out))
     print("F2 nnls-branch fraction", gen_F2(mrsgym, args.out))
     gen_F3(mrsgym, args.out); print("F3 done")
     gen_F4(mrsgym, args.out); print("F4 done")
     gen_F5(mrsgym, args.out); print("F5 done")
+    print("F5b rounds", gen_F5b(mrsgym, args.out))
     print("F6", gen_F6(args.out))
     print("F7", gen_F7(args.out))
     print("F8", gen_F8(args.out))
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write("Golden fixtures generated by tools/gen_golden.py from the reference's own Python\n"
                 "(numpy %s, scipy %s).  Data only: inputs and expected outputs.\n"
-                "F1 QuadControl cascade, F2 nnlsRPM, F3 MRS.calc_A, F4 history deques, F5 spawn,\n"
+                "F1 QuadControl cascade, F2 nnlsRPM, F3 MRS.calc_A, F4 history deques, F5 spawn (properties),\n"
+                "F5b MRS.generate_start_pos driven by a replay distribution (candidates, final layout, picks per round),\n"
                 "F6 full MRS.step() trajectories with pybullet replaced by the build's own oracle\n"
                 "integrator (pins everything except the Bullet integrator/contact: parity unpinned there),\n"
+                "F6c the same harness with the contact sweeps at a converged count (50) on bodies tumbling on the ground,\n"
                 "F7 the Reynolds flocking expert of examples/simulating_data (forward_batch, D=6/9, K=1..3),\n"
                 "F8 the flocking metrics of examples/simulating_data/helper/MRSAnalytics.py.\n"
                 % (np.__version__, scipy.__version__))

@@ -3,7 +3,7 @@
 # duration of each of the last 30 launches of the measured kernel and the gap in front of it.
 root=$(pwd); out="$root/gpurun_out/short_trace"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-dense-a --no-double-buffer > "$out/bench.json" 2> "$out/err.txt"
+rocprofv3 --kernel-trace --output-format csv -d "$out" -o run -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-dense-a --no-model-legs > "$out/bench.json" 2> "$out/err.txt"
 python3 - "$out/run_kernel_trace.csv" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].replace("void ", "").startswith("k_step<4")]

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-phase error quantiles of the teacher-forced runs (tests/util_teacher.py) on the literal BASELINE workloads:
+`python tools/teacher_probe.py [--steps 1000] [--envs 32] [--solver-iters K]` on the GPU box -> the table of DESIGN.md section 5
+(profiles/r04_teacher_forced.txt)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "mrs-gym_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import mrsgym_amd  # noqa: E402
+import util_teacher as ut  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--envs", type=int, default=32)
+    ap.add_argument("--configs", default="C2,C3,C4,C5")
+    ap.add_argument("--solver-iters", type=int, default=0)
+    a = ap.parse_args()
+    print("teacher-forced per-step error |GPU - oracle| (max over the 13 state words, relative above magnitude 1),")
+    print("oracle re-seeded from the GPU state every step; E = %d envs, %d steps; phases by the body's pre-step state" % (a.envs, a.steps))
+    for cfg in a.configs.split(","):
+        params = None
+        if a.solver_iters:
+            params = mrsgym_amd.default_params()
+            params.solver_iters = a.solver_iters
+        t0 = time.time()
+        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params,
+                   progress=lambda t: print("   ... %s step %d (%.0f s)" % (cfg, t, time.time() - t0), flush=True))
+        print("%s  N=%d  %s  solver_iters=%d  grounded at the end %.0f %%  adjacency/observation mismatches %d  visited %s"
+              % (cfg, r["N"], ut.CONFIGS[cfg]["atype"], int((params or mrsgym_amd.default_params()).solver_iters),
+                 100 * r["grounded_share"], r["adj_bad"], json.dumps(r["visited"])))
+        for ph in ut.PHASES:
+            q = ut.quantiles(r["err"][ph])
+            if q:
+                print("   %-7s n=%9d  50%% %.2e  99%% %.2e  99.9%% %.2e  max %.2e  at (t, env, agent) %s"
+                      % (ph, q["n"], q["q50"], q["q99"], q["q999"], q["max"], r["worst"][ph][1]))
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
