@@ -520,13 +520,20 @@ struct DownwashConst {
     float lg_alpha; // log2(c_alpha): folded into the exponent, alpha * e^x = rdz^2 * 2^(x log2 e + lg_alpha)
     float dw2, dw3;
     float pr32, dw1;
+    // A pair whose dxy^2 exceeds zero_c * beta^2 (beta = dw2 |dz| + dw3) contributes an EXACT float32 zero: the term is
+    // rdz^2 * exp2(lg_alpha - 0.7213 dxy^2 / beta^2) and v_exp_f32 returns 0 for arguments below -149 (-126 with denormal
+    // results flushed); zero_c puts the argument below -150 with the rounding of the two reciprocals and products (< 1e-6
+    // relative) to spare.  The pair loops of multi-wave envs skip a pass in which every lane's pairs are such (a wave vote).
+    float zero_c;
 };
+MRS_DEV float downwash_zero_c(float lg_alpha) { return (150.0f + (lg_alpha > 0.f ? lg_alpha : 0.f)) * (1.0f / 0.72134752f) * 1.00001f; }
 MRS_DEV DownwashConst downwash_const(const MrsParams &P)
 {
     DownwashConst c;
     c.pr32 = (float)P.prop_radius; c.dw1 = (float)P.dw1; c.dw2 = (float)P.dw2; c.dw3 = (float)P.dw3;
     c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
     c.lg_alpha = __builtin_log2f(c.c_alpha);
+    c.zero_c = downwash_zero_c(c.lg_alpha);
     return c;
 }
 MRS_DEV float downwash_pair_fast(float rx, float ry, float dz, const DownwashConst &c)
@@ -562,12 +569,12 @@ MRS_DEV float downwash_mag2(float d2, float adz, float dw2, float dw3, float lg_
 // arguments they would otherwise be re-read from the argument segment (s_load + wait) inside every pair once the
 // scalar registers run short, and moved to a VGPR per use (a VOP3 takes one SGPR).
 struct DownwashRegs {
-    float dw2, dw3, lg;
+    float dw2, dw3, lg, nzc; // nzc = -zero_c
 };
 MRS_DEV DownwashRegs downwash_regs(const DownwashConst &c)
 {
-    DownwashRegs r = {c.dw2, c.dw3, c.lg_alpha};
-    asm volatile("" : "+v"(r.dw2), "+v"(r.dw3), "+v"(r.lg));
+    DownwashRegs r = {c.dw2, c.dw3, c.lg_alpha, -c.zero_c};
+    asm volatile("" : "+v"(r.dw2), "+v"(r.dw3), "+v"(r.lg), "+v"(r.nzc));
     return r;
 }
 MRS_DEV float downwash_pair(float rx, float ry, float dz, float pr32, float dw1, float dw2, float dw3)

@@ -680,12 +680,25 @@ __device__ __forceinline__ f2 downwash_mag2_pk(f2 d2, f2 rz, const DownwashRegs 
     return pk_mul(pk_mul(rdz, rdz), ex);
 }
 
+// Does any lane of the wave have a pair in this pass (dxy^2 = d2, dz = rz, two neighbours) whose term is not an exact zero?
+// (DownwashConst.zero_c; a pair outside the 10 m cylinder or with a non-finite distance is deselected anyway.)  On the 16 m
+// grid of BASELINE config 4 nine passes in ten have none: six instructions and a scalar branch instead of the two
+// reciprocals, the exponential and the selects of two neighbours.
+__device__ __forceinline__ bool downwash_pass_live(f2 d2, f2 rz, const DownwashRegs &dr)
+{
+    const f2 beta = {__builtin_fmaf(dr.dw2, fabsf(rz.x), dr.dw3), __builtin_fmaf(dr.dw2, fabsf(rz.y), dr.dw3)};
+    const f2 t = pk_fma(pk_mul(beta, beta), splat(dr.nzc), d2); // > 0: dxy^2 > zero_c beta^2, the term is exactly 0
+    const bool live = (t.x <= 0.f && d2.x < 100.f) || (t.y <= 0.f && d2.y < 100.f);
+    return __builtin_amdgcn_ballot_w64(live) != 0;
+}
+
 // The downwash of an N = 64 env from its LDS tile (see tile64_write), evaluated once per unordered pair: see k_step.
 // t = the env's tile + lane.  Two neighbours per pass through the packed float32 instructions; the reciprocals, the
 // exponential and the selects stay per neighbour.  Per pair operation for operation the arithmetic of downwash_mag2;
 // the terms a lane keeps and the terms handed to it are summed separately (float32, flushed to float64 every 8 pairs).
 // hook(j), j = 0..14, runs ahead of the j-th pass: k_step spreads the state loads the loop does not need over the passes.
-template <class Hook>
+// SKIP (the blocks of multi-wave envs): passes without a live pair are voted out (downwash_pass_live); bit-identical sums.
+template <bool SKIP, class Hook>
 __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, float my_, float mz_, int lane4, const DownwashConst &dc, Hook &&hook)
 {
     const DownwashRegs dr = downwash_regs(dc);
@@ -715,10 +728,12 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
         f2 rx, ry, rz;
         tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
         const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
-        const f2 m = mag2(d2, rz);
-        trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
-        trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
-        keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+        if (!SKIP || downwash_pass_live(d2, rz, dr)) {
+            const f2 m = mag2(d2, rz);
+            trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
+            trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
+            keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+        } else trav = wave_ror1(wave_ror1(trav)); // two exact zeros on board: the word still travels its two lanes
         asm volatile("" : "+v"(keep)); // formed here, not sunk to the end of the loop
         if ((j & 3) == 3) { dkeep += (double)f32add(keep.x, keep.y); keep = f2{0.f, 0.f}; }
     }
@@ -754,10 +769,12 @@ __device__ __forceinline__ double downwash_cross(const float *tp, float mx_, flo
             f2 rx, ry, rz;
             tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
             const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
-            const f2 m = downwash_mag2_pk(d2, rz, dr);
-            trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
-            trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
-            keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+            if (downwash_pass_live(d2, rz, dr)) {
+                const f2 m = downwash_mag2_pk(d2, rz, dr);
+                trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
+                trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
+                keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
+            } else trav = wave_ror1(wave_ror1(trav));
             asm volatile("" : "+v"(keep));
         }
         dkeep += (double)f32add(keep.x, keep.y);
@@ -974,7 +991,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // the terms from the other waves arrive in the 128 floats a tile leaves free behind its three arrays
         if (doit) {
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
-            downwash_acc = downwash_ring64(my_tile + lane, mx, my, mz, lane << 2, A.dc, [](int) {});
+            downwash_acc = downwash_ring64<true>(my_tile + lane, mx, my, mz, lane << 2, A.dc, [](int) {});
             const DownwashRegs dr = downwash_regs(A.dc);
             if (nb >= 3) { // every pair with the next block
                 float *const ot = tile64(lds_tile, wt - b + (b + 1 == nb ? 0 : b + 1));
@@ -1075,7 +1092,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // env, so the whole wave is here.)
                 const int lane = tid & 63;
                 // tile + lane: neighbour (lane + k) mod 64 at offset k, no wrap; lane << 2 = ds_bpermute byte address of this lane
-                downwash_acc = downwash_ring64(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
+                downwash_acc = downwash_ring64<false>(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
                     if (!late_loads) return;
                     // (the controller memory the outer loop of the cascade wants right after this loop was tried here too,
                     // passes 10..14: no gain, 27.2 against 27.2 us per step, and spills in set_target_pos)
@@ -1792,6 +1809,12 @@ struct MrsHandle {
     int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
     unsigned long long *pair_rows; // device workspace [T][W]: the candidates per agent (StepArgs.pair_rows)
     bool big_lds[MRS_ACT_TARGET_ORI + 1]; // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device, per ACTION_TYPE
+    // The part of StepArgs that only depends on the parameters, the observation spec and the range (fill_common): kept from one
+    // call to the next -- a step of a small swarm (C2: 12 us of kernel) is host-bound, and the threshold search, the logarithm and
+    // the divisions of fill_common were ~0.4 us of every call.  Invalidated by mrs_set_params.
+    struct StepArgs *cached;
+    double cached_range;
+    int cached_fields[MRS_OBS_MAX_FIELDS], cached_n_obs;
 };
 
 static thread_local char g_err[256] = "";
@@ -1887,6 +1910,7 @@ extern "C" int mrs_set_params(MrsHandle *h, const MrsParams *params)
 {
     if (!h || !params) return fail(MRS_E_ARG, "mrs_set_params: NULL");
     h->P = *params;
+    if (h->cached) { delete h->cached; h->cached = nullptr; }
     double d[7];
     mrs_params_derived(params, d);
     h->hclip = d[6];
@@ -1932,6 +1956,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         const int v = atoi(sb);
         if ((v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) && v >= n_agents && n_agents <= 256) h->sblock = v;
     }
+    h->cached = nullptr;
     mrs_set_params(h, params);
     // internal workspace (never user-visible): contact counters + compacted contact list
     h->ws = nullptr; h->cs = nullptr; h->step_parity = 0;
@@ -1970,6 +1995,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
 extern "C" void mrs_destroy(MrsHandle *h)
 {
     if (!h) return;
+    if (h->cached) { delete h->cached; h->cached = nullptr; }
     if (h->ws || h->cs || h->pair_flag || h->pair_rows) {
         DeviceGuard dg(h->device);
         if (h->pair_flag) (void)hipFree(h->pair_flag);
@@ -1995,7 +2021,30 @@ static float d2_threshold(double comm_range)
     return t;
 }
 
+static int fill_common_uncached(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs, double comm_range, StepArgs &A);
 static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs, double comm_range, StepArgs &A)
+{
+    if (n_obs < 0 || n_obs > MRS_OBS_MAX_FIELDS || (n_obs > 0 && !obs_fields)) return fail(MRS_E_ARG, "bad observation field list");
+    bool hit = h->cached != nullptr && h->cached_n_obs == n_obs && (h->cached_range == comm_range || (std::isnan(h->cached_range) && std::isnan(comm_range)));
+    for (int i = 0; hit && i < n_obs; ++i) hit = h->cached_fields[i] == obs_fields[i];
+    if (!hit) {
+        if (!h->cached) h->cached = new (std::nothrow) StepArgs;
+        if (!h->cached) return fail(MRS_E_ARG, "out of host memory");
+        MrsBuffers none;
+        memset(&none, 0, sizeof(none));
+        const int rc = fill_common_uncached(h, &none, obs_fields, n_obs, comm_range, *h->cached);
+        if (rc) { delete h->cached; h->cached = nullptr; return rc; }
+        h->cached_range = comm_range; h->cached_n_obs = n_obs;
+        for (int i = 0; i < n_obs; ++i) h->cached_fields[i] = obs_fields[i];
+    }
+    A = *h->cached;
+    A.b = *b;
+    // the two members that depend on the call's buffers
+    A.n_obs = (n_obs > 0 && !b->obs) ? 0 : n_obs;
+    A.do_adj = (b->adj != nullptr) && !std::isnan(comm_range);
+    return 0;
+}
+static int fill_common_uncached(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fields, int n_obs, double comm_range, StepArgs &A)
 {
     memset(&A, 0, sizeof(A));
     A.P = h->P; A.b = *b; A.E = h->E; A.N = h->N; A.T = h->E * h->N; A.epb = h->epb; A.W = h->W; A.hclip = h->hclip;
@@ -2010,6 +2059,7 @@ static int fill_common(MrsHandle *h, const MrsBuffers *b, const int32_t *obs_fie
         c.pr32 = (float)h->P.prop_radius; c.dw1 = (float)h->P.dw1; c.dw2 = (float)h->P.dw2; c.dw3 = (float)h->P.dw3;
         c.c_alpha = c.dw1 * (0.25f * c.pr32) * (0.25f * c.pr32);
         c.lg_alpha = (float)std::log2((double)c.c_alpha);
+        c.zero_c = (150.0f + (c.lg_alpha > 0.f ? c.lg_alpha : 0.f)) * (1.0f / 0.72134752f) * 1.00001f; // downwash_zero_c
     }
     A.rc.inv_mass = 1.0 / h->P.mass; A.rc.inv_i0 = 1.0 / h->P.inertia[0]; A.rc.inv_i1 = 1.0 / h->P.inertia[1];
     A.rc.inv_i2 = 1.0 / h->P.inertia[2]; A.rc.inv_4kf = 1.0 / (4 * h->P.kf); A.rc.inv_dt = 1.0 / h->P.dt;

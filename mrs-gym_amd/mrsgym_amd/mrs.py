@@ -93,6 +93,10 @@ class MRS(_EnvBase):
         self.reward_fn = reward_fn if (reward_fn is not None) else (lambda **kwargs: 0.0)
         self.done_fn = done_fn if (done_fn is not None) else (lambda **kwargs: kwargs["steps_since_reset"] >= self.MAX_TIMESTEPS)
         self.info_fn = info_fn if (info_fn is not None) else (lambda **kwargs: {})
+        # the defaults by identity: step() inlines them (their results need no kwargs dict and no three Python calls -- a
+        # microsecond of the host's ~8 per step, which is what a small swarm's step waits for); a callback assigned later is seen
+        self._default_cbs = (self.reward_fn if reward_fn is None else None, self.done_fn if done_fn is None else None,
+                             self.info_fn if info_fn is None else None)
         self.update_fn = update_fn
         self.start_fn = start_fn
         if not isinstance(env, str):
@@ -552,12 +556,13 @@ class MRS(_EnvBase):
         E, N = self.N_ENVS, self.N_AGENTS
         atype = None
         if actions is not None:
-            actions = actions if isinstance(actions, torch.Tensor) else torch.tensor(np.asarray(actions))
-            actions = actions.detach()
-            if len(actions.shape) == 1:
+            if not isinstance(actions, torch.Tensor):
+                actions = torch.tensor(np.asarray(actions))
+            if actions.requires_grad:
+                actions = actions.detach()
+            if actions.dim() == 1:
                 actions = actions.reshape(self.N_AGENTS, self.ACTION_DIM)
-            mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
-            if mode == "sync" and bool(torch.isnan(actions).any()):
+            if (self.CHECK_NAN or ("sync" if E == 1 else "lazy")) == "sync" and bool(torch.isnan(actions).any()):
                 raise Exception('The given action contains NaN:\n %s' % str(actions))
             self.last_action = actions
             atype = ACTION_TYPE if ACTION_TYPE is not None else self.ACTION_TYPE
@@ -591,22 +596,32 @@ class MRS(_EnvBase):
             if dr is not None:
                 dr.committed()
             Ak = self.get_Ak()
-        mode = self.CHECK_NAN or ("sync" if E == 1 else "lazy")
-        if mode == "lazy" and (self._global_step & 255) == 255:   # _global_step: never zeroed by reset()
+        if (self._global_step & 255) == 255 and (self.CHECK_NAN or ("sync" if E == 1 else "lazy")) == "lazy":   # _global_step: never zeroed by reset()
             self._poll_errors()
-        # update function; draw_links is a GUI-only no-op here (MRS.py:259)
-        kw = dict(env=self.env, X=Xk, A=Ak, action=self.last_action, steps_since_reset=self.steps_since_reset)
-        if self.update_fn is not None:
-            self.update_fn(Xlast=self.last_obs, **kw)
-        reward = self.reward_fn(Xlast=self.last_obs, **kw)
-        self.last_obs = Xk
-        info = self.info_fn(Xlast=self.last_obs, **kw)   # sees Xlast == X, as upstream (MRS.py:264-266)
-        if want_A:
-            info["A"] = Ak
-        if self.RETURN_EVENTS:
-            info["keyboard_events"] = self.env.get_keyboard_events()
-            info["mouse_events"] = self.env.get_mouse_events()
-        done = self.done_fn(Xlast=self.last_obs, **kw)
+        dc = self._default_cbs
+        if self.update_fn is None and self.reward_fn is dc[0] and self.done_fn is dc[1] and self.info_fn is dc[2]:
+            # every callback is the reference's default (MRS.py:38-40): reward 0.0, info {}, done = steps >= MAX_TIMESTEPS
+            reward = 0.0
+            self.last_obs = Xk
+            info = {"A": Ak} if want_A else {}
+            if self.RETURN_EVENTS:
+                info["keyboard_events"] = self.env.get_keyboard_events()
+                info["mouse_events"] = self.env.get_mouse_events()
+            done = self.steps_since_reset >= self.MAX_TIMESTEPS
+        else:
+            # update function; draw_links is a GUI-only no-op here (MRS.py:259)
+            kw = dict(env=self.env, X=Xk, A=Ak, action=self.last_action, steps_since_reset=self.steps_since_reset)
+            if self.update_fn is not None:
+                self.update_fn(Xlast=self.last_obs, **kw)
+            reward = self.reward_fn(Xlast=self.last_obs, **kw)
+            self.last_obs = Xk
+            info = self.info_fn(Xlast=self.last_obs, **kw)   # sees Xlast == X, as upstream (MRS.py:264-266)
+            if want_A:
+                info["A"] = Ak
+            if self.RETURN_EVENTS:
+                info["keyboard_events"] = self.env.get_keyboard_events()
+                info["mouse_events"] = self.env.get_mouse_events()
+            done = self.done_fn(Xlast=self.last_obs, **kw)
         self.last_loop_time = time.monotonic()
         self.steps_since_reset += 1
         self._global_step += 1

