@@ -192,7 +192,7 @@ def main():
     # so the per-launch duration is sampled and the pair's cost amortised over the span.
     # Round 3: the spans cover the whole timed region (50 of every 50 launches; the driver's 20-step form: one span of 20).  With
     # spans of 10 the average came out 0.3 - 0.4 us ABOVE the wall-clock time per step of the same region -- the two records'
-    # own cost lands inside the span and was divided by 10 (tools/ev_span_test.sh: span 10: kernel 22.80 / step 22.46 us;
+    # own cost lands inside the span and was divided by 10 (tools/probes/ev_span_test.sh: span 10: kernel 22.80 / step 22.46 us;
     # span 25 ... 50: 22.29 / 22.28, 22.35 / 22.50) -- and a rocprofv3 kernel trace of the same run sat 0.9 us below it.
     EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
     EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "50")), EV_EVERY, args.steps))
@@ -277,7 +277,7 @@ def main():
     model = model_of(env)
     assert env._obs.fused, "cat(pos, vel) must take the fused observation path"
     # the torch kernels of rollin()'s grounded-share expression are loaded here, not at their first use between roll-in and
-    # warm-up (a code-object load is ~55 ms of host time with the GPU idle: kernel trace, tools/trace_bench.sh)
+    # warm-up (a code-object load is ~55 ms of host time with the GPU idle: kernel trace, tools/probes/trace_bench.sh)
     float((env.shard.pos[2] < 0.6).float().mean())
     # no collector pause between here and the end of the timed region (in its 20-step form, 0.5 ms, one pause would be a
     # tenth of it); collected now, while the GPU has nothing queued, not between roll-in and warm-up

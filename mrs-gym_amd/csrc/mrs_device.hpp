@@ -354,8 +354,13 @@ MRS_DEV float div_ctrl_dt(float x, float dt32, const Recips &K)
     const float q0 = f32mul(x, K.inv_ctrl_dt32);
     // the refinement is exact arithmetic on FINITE NORMAL quotients only: x = +-inf or an overflowing x r would give
     // fma(-dt, inf, x) = NaN where the division gives +-inf (a diverged env carries inf in the reference and in the oracle),
-    // and a subnormal quotient is rounded twice -- both go through the division proper
-    if (!(__builtin_fabsf(q0) <= 3.0e38f) || !(__builtin_fabsf(q0) >= 1.2e-38f)) return f32div(x, dt32);
+    // and a zero or subnormal first quotient loses the sign of zero / is rounded twice -- those go through the division
+    // proper.  One v_cmp_class_f32 (+-normal); measured against round 3's unguarded form: 22.95 / 23.01 against 22.51 / 22.62 us
+    // per step with two compares and an or, inside the noise with the class test (tools/abl_run.sh).
+#ifndef MRS_DIV_GUARD
+#define MRS_DIV_GUARD 1 // A/B switch: 0 = round 3's unguarded form
+#endif
+    if (MRS_DIV_GUARD && !__builtin_amdgcn_class(q0, 0x008 | 0x100)) return f32div(x, dt32);
     return __builtin_fmaf(__builtin_fmaf(-dt32, q0, x), K.inv_ctrl_dt32, q0);
 }
 
@@ -750,7 +755,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
     // Start of the sweeps (the oracle's contact_solve does the same): every active point carries the equal share of the
     // impulse that stops the mean closing velocity, l0 = m max(sum rhs, 0) / n^2 -- exact for a body lying flat, which
     // then needs no iteration; the sweeps correct it for everything else.  From a cold start 90 % of the grounded
-    // bodies needed 8-10 sweeps, with this start 86 % are done after the first pair (tools/sweeps_probe.py).
+    // bodies needed 8-10 sweeps, with this start 86 % are done after the first pair (tools/probes/sweeps_probe.py).
     {
         float nact = 0.f, rsum = 0.f;
 #pragma unroll
@@ -823,7 +828,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 #endif
         // ... or once a pair of sweeps has moved the impulses by at least half of what the pair before it did: 4 % of the
         // grounded bodies never get below the tolerance (the clamps of the friction pyramid chatter), ten sweeps leave them
-        // no better off than four, and each of them kept its whole wave of 64 in the loop (tools/sweeps_probe.py)
+        // no better off than four, and each of them kept its whole wave of 64 in the loop (tools/probes/sweeps_probe.py)
         if (moved >= MRS_CONTACT_STAG * prev_moved) break;
         prev_moved = moved;
     }

@@ -381,7 +381,7 @@ __device__ __forceinline__ void adj64_flag(const StepArgs &A, const float *t, fl
         // which of its pairs: neighbours k = 1..31 within range at bit k of hm, the antipode k = 32 in ht
         // (the same float32 operations as the pass, hence the same distances)
         // Unrolled, two neighbours per pass like the pass itself: the wave is alone on its SIMD by now and the launch waits for
-        // it -- as a rolled loop of 32 dependent LDS round trips this walk was 1.9 us (tools/timeline_simd.py: the seven latest
+        // it -- as a rolled loop of 32 dependent LDS round trips this walk was 1.9 us (tools/probes/timeline_simd.py: the seven latest
         // workgroups of a bench launch were the seven with a flagged env), now the reads are in flight together.
         uint32_t hm = 0;
         bool ht = false;
@@ -680,6 +680,16 @@ __device__ __forceinline__ f2 downwash_mag2_pk(f2 d2, f2 rz, const DownwashRegs 
     return pk_mul(pk_mul(rdz, rdz), ex);
 }
 
+// Round 4, built, bit-identical (same checksums), and measured WITHOUT gain -- left off: N = 256 x 1024 envs,
+// set_control, steady state: 47.8 / 48.1 us per step with the vote against 47.7 / 47.4 without (six sweeps: 45.8 / 45.5 against
+// 44.5 / 44.5).  The vote can only drop a pass in which all 64 lanes' pairs are exact zeros; that holds on the spawn grid (lane
+// offset k = a fixed grid displacement), but 700 steps of open-loop thrust scatter the swarm over tens of metres before it
+// comes down, the lane index no longer says anything about where an agent is, and with ~2 % of the pairs live a pass of 128
+// pairs has a live one nine times out of ten.  What would help there is a per-lane list of the live partners (a scan at ~16
+// instructions per pass either way); not built.
+#ifndef MRS_DW_SKIP
+#define MRS_DW_SKIP 0 // A/B switch (tools/abl_build.sh): 1 = vote out the passes of the multi-wave pair loops whose terms are all exact zeros
+#endif
 // Does any lane of the wave have a pair in this pass (dxy^2 = d2, dz = rz, two neighbours) whose term is not an exact zero?
 // (DownwashConst.zero_c; a pair outside the 10 m cylinder or with a non-finite distance is deselected anyway.)  On the 16 m
 // grid of BASELINE config 4 nine passes in ten have none: six instructions and a scalar branch instead of the two
@@ -769,7 +779,7 @@ __device__ __forceinline__ double downwash_cross(const float *tp, float mx_, flo
             f2 rx, ry, rz;
             tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
             const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
-            if (downwash_pass_live(d2, rz, dr)) {
+            if (!MRS_DW_SKIP || downwash_pass_live(d2, rz, dr)) {
                 const f2 m = downwash_mag2_pk(d2, rz, dr);
                 trav = f32add(wave_ror1(trav), theirs_of(m.y, rz.y, d2.y)); // k + 1
                 trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
@@ -865,17 +875,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const bool n64 = (AN == 64);
 
     const int tid = threadIdx.x;
-#ifdef MRS_TIMELINE // diagnostic build (tools/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
+#ifdef MRS_TIMELINE // diagnostic build (tools/probes/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
                     // boundaries into the rpm buffer, 16 floats per wave, instead of the rotor speeds
     const long long t_start = clock64();
     float *tl = A.b.rpm ? A.b.rpm + ((size_t)blockIdx.x * (BLOCK / 64) + (tid >> 6)) * 16 : nullptr;
 #define TL(k) do { if (tl && (tid & 63) == 0) tl[k] = (float)(clock64() - t_start); } while (0)
     if (tl && (tid & 63) == 0) tl[11] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFF); // wave start on the 100 MHz chip-wide clock
-    if (tl && (tid & 63) == 0) { // where the wave runs: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID (tools/timeline_simd.py)
+    if (tl && (tid & 63) == 0) { // where the wave runs: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID (tools/probes/timeline_simd.py)
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         tl[13] = (float)(hw & 0xFFFF); tl[14] = (float)(hw >> 16); tl[15] = (float)(xcc & 0xF);
     }
-#elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/isa_sections.py)
+#elif defined(MRS_MARKS) // analysis build: phase boundaries as comments in the assembly (tools/probes/isa_sections.py)
 #define TL(k) asm volatile("; MRS_MARK " #k)
 #else
 #define TL(k) do { } while (0)
@@ -991,7 +1001,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // the terms from the other waves arrive in the 128 floats a tile leaves free behind its three arrays
         if (doit) {
             const float mx = (float)p[0], my = (float)p[1], mz = (float)p[2];
-            downwash_acc = downwash_ring64<true>(my_tile + lane, mx, my, mz, lane << 2, A.dc, [](int) {});
+            downwash_acc = downwash_ring64<(MRS_DW_SKIP != 0)>(my_tile + lane, mx, my, mz, lane << 2, A.dc, [](int) {});
             const DownwashRegs dr = downwash_regs(A.dc);
             if (nb >= 3) { // every pair with the next block
                 float *const ot = tile64(lds_tile, wt - b + (b + 1 == nb ? 0 : b + 1));
@@ -1381,7 +1391,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                     const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
                     const double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
                     const double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
-#ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/sweeps_probe.py); the run's physics is void
+#ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/probes/sweeps_probe.py); the run's physics is void
                     float dg[2] = {0.f, 0.f};
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw, dg);
                     if (wb.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
@@ -1935,7 +1945,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     h->W = (n_agents + 63) / 64;
     const char *split = getenv("MRS_STEP_SPLIT");
     h->fused = (h->block == 256) && !(split && split[0] == '1');
-    // N = 64: eight envs (waves) per workgroup.  Measured at the bench size (tools/abl_sblock.sh, same build, us per step):
+    // N = 64: eight envs (waves) per workgroup.  Measured at the bench size (tools/probes/abl_sblock.sh, same build, us per step):
     // 64 threads 32.1, 128: 30.5, 256: 29.0, 512: 27.5, 1024: 29.6 -- two workgroups of eight waves per CU pool their
     // grounded bodies over more envs (fewer, fuller solver waves) and put two waves of the same hand-off group on each SIMD
     // ... as long as that still gives every CU a workgroup: a swarm of fewer than 8 x CUs envs takes the largest workgroup

@@ -315,7 +315,7 @@ class MRS(_EnvBase):
         (mrs_spawn_from).  The samples come from a copy of the distribution whose parameters live on the device when one
         can be made (_dist_to: torch's own distributions, CombinedDistribution, TransformedDistribution) -- then for every
         env, selected or not, with no host round trip (a loop that resets a few envs every step, AUTO_RESET, spends 0.7
-        instead of 7 ms per step that way: E = 512, N = 12, tools/profile_autoreset.py) -- and from the caller's own
+        instead of 7 ms per step that way: E = 512, N = 12, tools/probes/profile_autoreset.py) -- and from the caller's own
         object on the host otherwise, for the selected envs only.  Writes positions only."""
         sp, E, N, sh = self.START_POS, self.N_ENVS, self.N_AGENTS, self.shard
         dev_dist, per_agent = self._start_pos_on_device()

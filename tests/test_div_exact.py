@@ -1,5 +1,5 @@
 """mrs_device.hpp:div_ctrl_dt -- float32 division by the controller's DT as multiply + two fused multiply-adds -- is the
-correctly rounded quotient (QuadControl.py:62 divides float32 by DT).  tools/divcheck.py is the exhaustive form (all 3.8e9
+correctly rounded quotient (QuadControl.py:62 divides float32 by DT).  tools/probes/divcheck.py is the exhaustive form (all 3.8e9
 finite x, a minute); here: 4M random bit patterns plus the neighbourhoods of powers of two, for the default DT and two more."""
 import numpy as np
 import pytest
@@ -23,12 +23,12 @@ def test_fma_division_by_ctrl_dt_is_correctly_rounded(dt):
     ok = np.isfinite(want) & (np.abs(want) > 1e-30)
     assert np.array_equal(q1[ok], want[ok])
     # outside the refinement's domain the kernel takes the division proper: +-inf, quotients that overflow
-    # (near FLT_MAX) or are subnormal.  The guard is `1.2e-38 <= |q0| <= 3.0e38`; inside it the refinement must be exact
-    # -- checked above for |want| > 1e-30 -- and everything outside it must be caught.
+    # (near FLT_MAX), are zero or subnormal.  The guard is "the first quotient q0 is a normal number" (v_cmp_class_f32); inside
+    # it the refinement must be exact -- checked above for |want| > 1e-30 -- and everything outside it must be caught.
     big = np.array([np.inf, -np.inf, 3.4e38, -3.4e38, 3.3e36, 2.9e36, 1e-40, -1e-40, 1.3e-40, 0.0], np.float32)
     with np.errstate(all="ignore"):
         q0b = (big.astype(np.float64) * r64).astype(np.float32)
-        guarded = ~((np.abs(q0b) <= np.float32(3.0e38)) & (np.abs(q0b) >= np.float32(1.2e-38)))
+        guarded = ~(np.isfinite(q0b) & (np.abs(q0b) >= np.finfo(np.float32).tiny))
         wantb = (big.astype(np.float64) / d64).astype(np.float32)
         q1b = (q0b.astype(np.float64) + (big.astype(np.float64) - d64 * q0b.astype(np.float64)) * r64).astype(np.float32)
     assert guarded[0] and guarded[1] and guarded[-1]                        # inf, -inf, 0

@@ -155,7 +155,7 @@ def test_north_star_tolerance_1000_steps(atype):
 def test_north_star_tolerance_independent_targets():
     """The same 1e-4 / 1000-step bar with INDEPENDENT per-agent velocity targets (coherent=False: every quadcopter its own
     U[-0.4, 0.4]^3 m/s target, resampled every 50 steps, vertical sign alternating so that nobody reaches the ground), spawn
-    yaw up to +-1.0 rad, on a 2 m grid so that nobody passes through a neighbour's downwash cone.  Measured (tools/ns_probe.py):
+    yaw up to +-1.0 rad, on a 2 m grid so that nobody passes through a neighbour's downwash cone.  Measured (tools/probes/ns_probe.py):
     3e-7 here; with |yaw| <= 1.2 the same run is at 1e-2 after 1000 steps without any body touching the ground -- the
     reference's attitude loop (world-frame angular velocity in the body-rate D term, Quadcopter.py:54) is marginally stable
     there and amplifies the float32-level differences between the two implementations (profiles/r03_readme_stability.txt:

@@ -1,7 +1,7 @@
 """k_contact cost split on the bench workload (diagnostic): snapshot the C3 swarm at step 600, then time ONE step
 from that snapshot with different solver_iters / with the contact pass disabled."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

@@ -3,7 +3,7 @@ r = RN(1 / d) equals the correctly rounded quotient for EVERY finite float32 x (
 float64 stands in for the fused operations: d q0 (24 x 24 bits) and r rem are exact in float64, and rounding a float64
 result of +, -, x, / to float32 is innocuous double rounding (53 >= 2 * 24 + 2).
 
-    python tools/divcheck.py [d]          (~1 minute, numpy)"""
+    python tools/probes/divcheck.py [d]          (~1 minute, numpy)"""
 import sys, time
 import numpy as np
 d = np.float32(float(sys.argv[1]) if len(sys.argv) > 1 else 0.01)

@@ -4,7 +4,7 @@ Captures 2 consecutive mrs_step calls (the contact counters alternate by step pa
 steps makes a replayable unit) into a torch CUDAGraph on a side stream and compares stream time per step
 with plain launches.  Workload = bench.py's (C3)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

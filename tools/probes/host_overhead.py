@@ -3,7 +3,7 @@
 The launch loop is timed WITHOUT a trailing synchronize over a burst short enough that the HIP queue never
 fills (the host runs ahead of the GPU), so the figure is host time only."""
 import os, sys, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from util_scenarios import grid_spawn

@@ -1,6 +1,6 @@
 """Diagnostic: where the host time of one MRS.step() goes (cProfile over the bench loop, GPU box)."""
 import cProfile, os, pstats, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from util_scenarios import ActionStream, grid_spawn

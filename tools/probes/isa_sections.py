@@ -1,12 +1,12 @@
 """Diagnostic: static VALU instruction count per phase of k_step<set_target_vel> for the N = 64 instantiation.
 
-    python tools/isa_sections.py [extra -D flags]
+    python tools/probes/isa_sections.py [extra -D flags]
 
 Compiles mrs_kernels.hip with -DMRS_MARKS (phase boundaries as '; MRS_MARK k' comments; the generic-N branches of the
 run-time-N kernel are in the listing too, so the static counts are upper bounds of what an N = 64 wave executes) to assembly and histograms the vector instructions between consecutive marks, in layout order.
 The contact-sweep loop body is counted once (it runs up to solver_iters times)."""
 import collections, os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 flags = sys.argv[1:]
 out = "/tmp/isa_sections.s"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DMRS_MARKS",

@@ -1,6 +1,6 @@
 """Diagnostic: step time of one (E, N, action type) configuration; MRS_STEP_BLOCK / MRS_HIP_LIB select the build."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

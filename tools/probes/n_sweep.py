@@ -1,7 +1,7 @@
 """Diagnostic: step every ACTION_TYPE at awkward swarm sizes (workgroup tails, ring exchange odd/even, 1024-thread path)
 and check against the CPU oracle for a few steps."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd, oracle
 from util_scenarios import ActionStream, grid_spawn

@@ -1,7 +1,7 @@
 """Diagnostic: per-100-step kernel time of the bench workload through env.step() (history rings, rotating output slots)
 and through SwarmShard.step_ptr with fixed output buffers, same spawn and action stream."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix + stall counters of the step kernel at steady state (GPU box; one rocprofv3 --pmc run per counter group,
-# kernel trace only).  usage: tools/pmc_mix.sh <tag> [lib.so]   -> gpurun_out/pmc_<tag>/<group>/
+# kernel trace only).  usage: tools/probes/pmc_mix.sh <tag> [lib.so]   -> gpurun_out/pmc_<tag>/<group>/
 set -e
 tag=$1; lib=${2:-}
 root=$(pwd)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One rocprofv3 counter pass over a short bench run (GPU box; counters in their own run, kernel trace only).
-# usage: tools/pmc_pass.sh <tag> <counter> [<counter> ...]   -> gpurun_out/pmc_<tag>/
+# usage: tools/probes/pmc_pass.sh <tag> <counter> [<counter> ...]   -> gpurun_out/pmc_<tag>/
 set -e
 tag=$1; shift
 root=$(pwd)

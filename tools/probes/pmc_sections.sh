@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dynamic VALU instructions per wave of the step kernel with parts of the step switched off (GPU box; one rocprofv3
-# --pmc pass per configuration).  usage: tools/pmc_sections.sh <tag> <lib.so>  -> gpurun_out/pmc_<tag>/<config>/
+# --pmc pass per configuration).  usage: tools/probes/pmc_sections.sh <tag> <lib.so>  -> gpurun_out/pmc_<tag>/<config>/
 set -e
 tag=$1; lib=$2
 root=$(pwd)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One rocprofv3 counter pass over tools/steady_bench.py (GPU box; counters in their own run, kernel trace only).
-# usage: tools/pmc_steady.sh <tag> <counter> [<counter> ...]   -> gpurun_out/pmc_<tag>/, summary on stdout
+# usage: tools/probes/pmc_steady.sh <tag> <counter> [<counter> ...]   -> gpurun_out/pmc_<tag>/, summary on stdout
 set -e
 tag=$1; shift
 root=$(pwd)

@@ -1,6 +1,6 @@
 """Diagnostic: host-side profile (cProfile) of a vectorised AUTO_RESET loop with a user START_POS distribution."""
 import os, sys, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import torch, mrsgym_amd
 from mrsgym_amd.util import CombinedDistribution

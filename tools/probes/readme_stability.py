@@ -1,6 +1,6 @@
 """The leading open risk of SURVEY.md rows I/G, as an experiment (CPU oracle only; no GPU, no reference import).
 
-    python tools/readme_stability.py            -> profiles/r03_readme_stability.txt
+    python tools/probes/readme_stability.py            -> profiles/r03_readme_stability.txt
 
 The reference's README example (README.md:14-33): N_AGENTS = 3, ACTION_TYPE = set_target_vel with the constant target
 [0.5, 0, 0], default START_POS (z in [1, 3]) and default START_ORI (roll = pitch = 0, yaw ~ U[-pi/2, pi/2], MRS.py:54).
@@ -16,7 +16,7 @@ Survival = the share of quadcopters that are still above z = 0.8 after 1000 step
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 
@@ -61,7 +61,7 @@ def survival(yaw_max, inertia, ang_damp, use_gyro, seed=0):
 
 def main():
     out = []
-    out.append("# tools/readme_stability.py: README.md:14-33 on the CPU oracle, %d envs x %d agents, %d steps; survival (z > 0.8) / holding v_x = 0.5 +- 0.05" % (E, N, STEPS))
+    out.append("# tools/probes/readme_stability.py: README.md:14-33 on the CPU oracle, %d envs x %d agents, %d steps; survival (z > 0.8) / holding v_x = 0.5 +- 0.05" % (E, N, STEPS))
     out.append("%-32s %-9s %-5s | %-17s %-17s %-17s" % ("inertia", "ang_damp", "gyro", "|yaw| <= pi/2", "|yaw| <= 1.2", "|yaw| <= 0.8"))
     for name, I in inertia_candidates():
         for ad in (0.04, 0.0):

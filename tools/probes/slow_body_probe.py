@@ -2,7 +2,7 @@
 one step of the steady bench workload: tilt (R22), |w|, |v_xy| of the pre-step state, and the sweep count of the
 previous step."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

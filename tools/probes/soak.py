@@ -2,7 +2,7 @@
 state bitwise equal between the two runs; (2) a vectorised data-generation loop with AUTO_RESET (masked device spawn every few
 steps, which marks only those envs' contact flags unknown) for STEPS steps: no exception, spawn separation kept, finite state."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

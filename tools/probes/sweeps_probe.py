@@ -3,7 +3,7 @@ In that build the solver writes, per solved body, [first even sweep count at whi
 of sweeps its wave executed into planes 0 / 1 of the controller memory (set_target_pos leaves those planes ... no:
 the probe uses ACTION_TYPE None, which touches no controller memory)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

@@ -2,11 +2,11 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -DMRS_TIMELINE \
           mrs-gym_amd/csrc/mrs_kernels.hip -o build/abl/libmrs_tl.so
-    MRS_HIP_LIB=build/abl/libmrs_tl.so python tools/timeline_probe.py        (on the GPU box)
+    MRS_HIP_LIB=build/abl/libmrs_tl.so python tools/probes/timeline_probe.py        (on the GPU box)
 
 In that build lane 0 of every wave writes clock64() deltas at the phase boundaries into the rpm buffer."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT

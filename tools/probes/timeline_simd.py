@@ -1,8 +1,8 @@
-"""Diagnostic (MRS_TIMELINE build, see tools/timeline_probe.py): how the four waves that share a SIMD progress against each
+"""Diagnostic (MRS_TIMELINE build, see tools/probes/timeline_probe.py): how the four waves that share a SIMD progress against each
 other, and the waves of one workgroup against each other -- the skew that the workgroup barriers of the contact hand-off
 turn into waiting.  Uses the per-wave HW_ID / XCC_ID stamps."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'mrs-gym_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np, torch, mrsgym_amd
 from mrsgym_amd.native import ACT
