@@ -362,6 +362,22 @@ def main():
         per_rank = E * N * 6 * 4
         extra["no_exchange"] = {"value": agent_steps / n_elapsed, "unit": "agent-steps/s", "ms_per_step": n_elapsed / args.steps * 1e3,
                                 "what": "the same K steps without the all-gather: step() itself has no exchange between shards"}
+        # A consumer that needs the joint observation every k-th step only (ObsAllGather(every=k)), and the one-shot form of the
+        # exchange (grouped point-to-point operations) -- beside `value`, each in its own timed region;
+        # a leg that cannot run on this box says why instead of taking the bench down
+        for key, kw in (("gather_every_4", dict(every=4)), ("gather_every_16", dict(every=16)), ("direct_p2p", dict(mode="direct"))):
+            try:
+                saved = gather
+                gather = mdist.ObsAllGather(E, N, 6, dev, **kw)
+                g_elapsed, _, _ = timed_region(env, args.rollin, True)
+                extra[key] = {"value": agent_steps / g_elapsed, "unit": "agent-steps/s", "ms_per_step": g_elapsed / args.steps * 1e3,
+                              "what": {"gather_every_4": "the joint observation gathered on every 4th step only",
+                                       "gather_every_16": "the joint observation gathered on every 16th step only",
+                                       "direct_p2p": "every step, as one grouped batch of point-to-point sends / receives (the one-shot form)"}[key]}
+            except Exception as exc:          # noqa: BLE001 -- reported, never fatal
+                extra[key] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
+            finally:
+                gather = saved
         floor_ms = per_rank * (world - 1) / (min(world - 1, 7) * 76e9) * 1e3
         one_gpu_step_ms = n_elapsed / args.steps * 1e3
         extra["obs_allgather"] = {"bytes_sent_per_rank_per_step": per_rank * (world - 1), "bytes_received_per_rank_per_step": per_rank * (world - 1),

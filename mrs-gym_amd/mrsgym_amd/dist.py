@@ -6,6 +6,13 @@ joint observation.  The reference has no distributed code
 
 The gather runs on a side stream and is double-buffered: step t+1's kernel overlaps gather t.
 Backend: torch.distributed ("nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+
+Two forms of the exchange (MRS_DIST_ALLGATHER = "collective" | "direct", or ObsAllGather(mode=...)):
+  collective  one all_gather_into_tensor; ring or direct is RCCL's choice (the default: the form every round has run);
+  direct      SURVEY.md section 5's one-shot form spelled out -- every rank sends its slice to each of its peers and receives
+              theirs straight into place, one grouped batch of point-to-point operations (RCCL: one ncclGroup, all seven xGMI
+              links of a GPU driven at once, no hop through a neighbour; no zero-padding for unequal shards either).
+A consumer that needs the joint tensor only every k-th step says so (every=k): the steps in between exchange nothing.
 """
 import os
 
@@ -46,8 +53,14 @@ class ObsAllGather:
     """all-gather of the ranks' (E_local, N, D) slices into (sum of E_local, N, D) in rank order, overlapped with compute.
     The shards may differ in size (E not divisible by the world size)."""
 
-    def __init__(self, e_local, n_agents, d, device, group=None, buffers=2):
+    def __init__(self, e_local, n_agents, d, device, group=None, buffers=2, mode=None, every=1):
         self.group = group
+        self.mode = mode or os.environ.get("MRS_DIST_ALLGATHER", "collective")
+        if self.mode not in ("collective", "direct"):
+            raise ValueError("ObsAllGather mode must be 'collective' or 'direct', got %r" % (self.mode,))
+        self.every = max(1, int(every))
+        self.calls = 0          # gather() calls so far: the exchange runs on calls every-1, 2*every-1, ...
+        self.latest = None      # the buffer of the last exchange (what a call in between returns)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -63,7 +76,12 @@ class ObsAllGather:
             self.sizes = [self.e_local]
         self.offsets = [sum(self.sizes[:r]) for r in range(self.world)]
         self.e_max = max(self.sizes)
-        self.uneven = min(self.sizes) != self.e_max
+        self.uneven = min(self.sizes) != self.e_max and self.mode == "collective"   # the direct form sends exact slices
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.mode == "direct" and self.collective and self.world > 1 and torch.device(device).type == "cuda" \
+                and dist.get_backend(group) != "nccl":
+            raise RuntimeError("ObsAllGather(mode='direct') on GPU tensors needs the nccl (RCCL) backend; '%s' carries "
+                               "point-to-point operations for host tensors only" % dist.get_backend(group))
         self.out = [torch.empty(sum(self.sizes), n_agents, d, dtype=torch.float32, device=self.device) for _ in range(buffers)]
         # unequal shards: the collective needs equal contributions, so every rank sends e_max envs (its slice, zero-padded)
         # and the valid parts are compacted into `out` behind the collective, on the same side stream
@@ -77,8 +95,25 @@ class ObsAllGather:
         for r in range(self.world):
             self.out[k][self.offsets[r]:self.offsets[r] + self.sizes[r]].copy_(self.padded[k][r * self.e_max:r * self.e_max + self.sizes[r]])
 
+    def _p2p(self, out, src):
+        """The one-shot form: this rank's slice to every peer, every peer's slice into its place in `out` -- one grouped batch."""
+        me = self.rank
+        out[self.offsets[me]:self.offsets[me] + self.sizes[me]].copy_(src)
+        ops = []
+        for r in range(self.world):
+            if r == me or self.sizes[r] == 0:
+                continue
+            ops.append(dist.P2POp(dist.irecv, out[self.offsets[r]:self.offsets[r] + self.sizes[r]], r, group=self.group))
+        if self.sizes[me] > 0:
+            for r in range(self.world):
+                if r != me:
+                    ops.append(dist.P2POp(dist.isend, src, r, group=self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
     def gather(self, newest):
         """Start gathering `newest` (contiguous (E_local,N,D)); returns the output buffer, complete after wait().
+        With every = k > 1 only every k-th call exchanges anything; the calls in between return the buffer of the last
+        exchange (None before the first one) and cost nothing.
 
         Ordering (GPU): the collective runs on a side stream behind an event recorded on the caller's stream NOW, so
         it starts after the step kernel that wrote `newest` AND after everything the caller has enqueued so far --
@@ -87,12 +122,16 @@ class ObsAllGather:
         `newest` is a history-ring slot that the step kernel overwrites HISTORY_SLOTS - K steps later, so `buffers`
         must stay below that (2 against >= K + 1 by construction of HistoryRing).  A consumer must call wait() (or
         use its own wait_event on done[k]) before reading the returned buffer."""
+        self.calls += 1
+        if self.calls % self.every:
+            return self.latest
         k = self.k
         self.k = (k + 1) % len(self.out)
-        out = self.out[k]
+        out = self.latest = self.out[k]
         if not self.collective:
             out.copy_(newest)
             return out
+        direct = self.mode == "direct"
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
             if self.done[k] is not None:
@@ -105,12 +144,19 @@ class ObsAllGather:
             ready.record(cur)                                            # the step kernel that wrote `newest`
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                dist.all_gather_into_tensor(self.padded[k] if self.uneven else out, src, group=self.group)
+                if direct:
+                    for w in self._p2p(out, src):
+                        w.wait()                                         # RCCL: stream-ordered on the side stream, not a host wait
+                else:
+                    dist.all_gather_into_tensor(self.padded[k] if self.uneven else out, src, group=self.group)
                 if self.uneven:
                     self._compact(k)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             self.done[k] = ev
+        elif direct:
+            for w in self._p2p(out, newest.contiguous()):
+                w.wait()
         elif self.uneven:
             self.stage[k][:self.e_local].copy_(newest)
             dist.all_gather(list(self.padded[k].chunk(self.world, dim=0)), self.stage[k], group=self.group)

@@ -46,7 +46,7 @@ def _actions():
     return [acts(t) for t in range(STEPS)]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="collective", every=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from mrsgym_amd import dist as mdist
     r, w, _ = mdist.init_from_env(backend="gloo")
@@ -54,12 +54,17 @@ def _worker(rank, world, port, out_dir):
     lo, hi = mdist.shard_range(E_TOTAL, rank, world)
     all_actions = _actions()
     sw, obs = _run_block(lo, hi, all_actions)
-    gather = mdist.ObsAllGather(hi - lo, N, 6, "cpu")
+    gather = mdist.ObsAllGather(hi - lo, N, 6, "cpu", mode=mode, every=every)
     joint = []
     for t in range(STEPS):
         out = gather.gather(torch.from_numpy(obs[t]).contiguous())
         gather.wait()
-        joint.append(out.clone().numpy())
+        if every == 1 or t % every == every - 1:
+            joint.append(out.clone().numpy())
+        elif t < every - 1:
+            assert out is None                                        # nothing has been exchanged yet
+        else:
+            assert np.array_equal(out.numpy(), joint[-1])             # between exchanges: the last joint tensor
     state = mdist.gather_global_state(torch.from_numpy(np.concatenate([sw.pos, sw.quat, sw.vel, sw.angvel], -1)))
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist.npz"), joint=np.stack(joint), state=state.numpy())
@@ -78,12 +83,15 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_run_equals_single_process_bitwise(tmp_path):
+@pytest.mark.parametrize("mode,every", [("collective", 1), ("direct", 1), ("direct", 4), ("collective", 5)])
+def test_two_rank_run_equals_single_process_bitwise(tmp_path, mode, every):
+    """mode: the all-gather collective, or the one-shot form (every rank sends its slice to every peer, grouped point-to-point
+    operations: SURVEY.md section 5); every = k: only every k-th step exchanges the joint observation."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode, every), nprocs=2, join=True)
     d = np.load(os.path.join(str(tmp_path), "dist.npz"))
     sw, obs = _run_block(0, E_TOTAL, _actions())
-    assert np.array_equal(d["joint"], np.stack(obs))                      # gathered joint observation, every step
+    assert np.array_equal(d["joint"], np.stack(obs)[every - 1::every])    # gathered joint observation, every k-th step
     want = np.concatenate([sw.pos, sw.quat, sw.vel, sw.angvel], -1)
     assert np.array_equal(d["state"], want)                               # concatenated shard state == single run
 
@@ -93,3 +101,7 @@ def test_single_process_gather_is_identity():
     g = ObsAllGather(3, 4, 6, "cpu")
     x = torch.randn(3, 4, 6)
     assert torch.equal(g.gather(x), x)
+    g = ObsAllGather(3, 4, 6, "cpu", mode="direct", every=3)
+    assert g.gather(x) is None and g.gather(x) is None and torch.equal(g.gather(x), x) and torch.equal(g.gather(x + 1), x)
+    with pytest.raises(ValueError):
+        ObsAllGather(3, 4, 6, "cpu", mode="ring")

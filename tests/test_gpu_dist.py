@@ -28,13 +28,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("ranks", [2, 1])
-def test_product_ranks_equal_single_gpu_bitwise(tmp_path, ranks):
+@pytest.mark.parametrize("ranks,mode", [(2, "collective"), (1, "collective"), (1, "direct"), (2, "direct")])
+def test_product_ranks_equal_single_gpu_bitwise(tmp_path, ranks, mode):
     """ranks = 2: see the module text.  ranks = 1: the same worker as ONE rank, which always sits on RCCL (backend "nccl") --
     on the one-GPU boxes of this pool the only way the RCCL leg of ObsAllGather / gather_global_state (communicator set-up,
     all_gather_into_tensor on the side stream, the event hand-shake with the step stream) runs at all."""
     import mrsgym_amd
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "direct" and ranks > 1 and torch.cuda.device_count() < ranks:
+        pytest.skip("the one-shot form (grouped point-to-point operations) needs RCCL, i.e. one device per rank; its logic runs on "
+                    "the CPU in tests/test_dist_gloo.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRS_DIST_ALLGATHER=mode)
     if ranks == 1:
         env["MRS_DIST_FORCE"] = "1"             # mrsgym_amd.dist: the collective path with one rank
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",

@@ -593,6 +593,11 @@ def test_bench_contract_single_and_two_ranks():
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["unit"] == "agent-steps/s"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["config"]["workload"]
     assert d["rollin_steps"] == 700 and d["dense_a"]["value"] > 0 and d["dense_a"]["ms_per_step"] > 0
+    # the fidelity knobs `value` was measured with (the library's defaults) and the two legs beside it
+    m = d["config"]["model"]
+    assert (m["solver_iters"], m["round_euler_readback"], m["rest_shortcut"], m["pair_contact"]) == (10, 0, 1, 1)
+    assert d["literal"]["model"]["round_euler_readback"] == 1 and d["literal"]["model"]["rest_shortcut"] == 0 and d["literal"]["model"]["solver_iters"] == 10
+    assert d["solver6"]["model"]["solver_iters"] == 6 and d["literal"]["kernel_ms"] > 0 and 0 < d["solver6"]["roofline_frac"] < 1
     env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
@@ -606,6 +611,9 @@ def test_bench_contract_single_and_two_ranks():
     assert "all-gather" in d2["config"]["parallelism"]
     assert d2["no_exchange"]["value"] > 0 and d2["obs_allgather"]["bytes_sent_per_rank_per_step"] == 64 * 64 * 6 * 4
     assert d2["obs_allgather"]["xgmi_floor_ms"] > 0
+    # gathered every k-th step only: first-class legs; the one-shot form needs RCCL (one device per rank) and says so here
+    assert d2["gather_every_4"]["value"] > 0 and d2["gather_every_16"]["value"] > 0
+    assert d2["direct_p2p"]["value"] is None and "nccl" in d2["direct_p2p"]["error"]
 
 
 def test_handle_on_a_device_that_is_not_the_current_one():
