@@ -324,41 +324,72 @@ struct ProxArgs {
     size_t T;
 };
 
-// Object.get_dist (Object.py:119-133) for every ordered pair of an env + every quadcopter against the ground:
-// one workgroup per env, lanes stride over (i, j), j = N being the ground.  Pairs whose bounding spheres are already
-// further apart than max_dist are reported as +inf without running GJK (the reference's MAX_DIST returns nothing there).
+// Object.get_dist (Object.py:119-133) for every ordered pair of an env + every quadcopter against the ground: one workgroup per
+// env.  Pairs whose bounding spheres are already further apart than max_dist are reported as +inf without running GJK (the
+// reference's MAX_DIST returns nothing there).
+// Round 4: (i) every UNORDERED pair goes through GJK once -- the iteration for (j, i) is the exact mirror image of the one for
+// (i, j): v -> -v swaps the two support points, every simplex test is a dot product of two negated vectors -- and both
+// directions are written from it, closest points swapped; (ii) the pairs that survive the cull are COMPACTED: chunks of 1024
+// candidate pairs are tested first (one compare each) and the survivors appended to an LDS list, which the lanes then take
+// densely.  Before, a surviving pair kept its whole wave waiting for the ~10^3 float64 instructions of its GJK while the
+// other 63 lanes had nothing to do -- with a contact-range cull (collisions, get_contact_points: a handful of survivors per
+// env) that was most of the 646 us the call took at N = 64 x 4096 (profiles/r03_sensor_bench.txt).
+constexpr int PROX_CHUNK = 1024;
 __global__ __launch_bounds__(256) void k_proximity(const ProxArgs S)
 {
     extern __shared__ double lc[];
+    __shared__ int s_n;
+    __shared__ unsigned s_list[PROX_CHUNK]; // i << 16 | j, i < j
     const int e = blockIdx.x, N = S.N;
     const size_t a0 = (size_t)e * N;
     stage_cylinders(S.b, S.T, a0, N, lc);
     __syncthreads();
     const double bound = sqrt(S.rc * S.rc + S.hl * S.hl);
-    for (int idx = threadIdx.x; idx < N * (N + 1); idx += blockDim.x) {
-        const int i = idx / (N + 1), j = idx - i * (N + 1);
-        const Cyl me = {mk(lc[6 * i], lc[6 * i + 1], lc[6 * i + 2]), mk(lc[6 * i + 3], lc[6 * i + 4], lc[6 * i + 5])};
-        D3 pa = me.c, pb = me.c;
-        double d = 0;
-        if (j == N) {
+    auto cyl = [&](int i) { return Cyl{mk(lc[6 * i], lc[6 * i + 1], lc[6 * i + 2]), mk(lc[6 * i + 3], lc[6 * i + 4], lc[6 * i + 5])}; };
+    auto put = [&](int i, int j, double d, const D3 &pa, const D3 &pb) {
+        const size_t o1 = (a0 + i) * (size_t)(N + 1) + j;
+        S.dist[o1] = (float)d;
+        if (S.p_self) { S.p_self[3 * o1] = (float)pa.x; S.p_self[3 * o1 + 1] = (float)pa.y; S.p_self[3 * o1 + 2] = (float)pa.z; }
+        if (S.p_other) { S.p_other[3 * o1] = (float)pb.x; S.p_other[3 * o1 + 1] = (float)pb.y; S.p_other[3 * o1 + 2] = (float)pb.z; }
+    };
+    // the diagonal and the ground column: closed form, one lane each
+    for (int idx = threadIdx.x; idx < 2 * N; idx += blockDim.x) {
+        const int i = idx >> 1;
+        const Cyl me = cyl(i);
+        if (idx & 1) {
             // lowest point of the cylinder = support point along -z (the middle of the lowest line / cap when degenerate)
             const double az = me.a.z;
             D3 low = me.c + (az > 1e-12 ? -S.hl : (az < -1e-12 ? S.hl : 0.0)) * me.a;
             const D3 rad = mk(0, 0, -1) - (-az) * me.a;
             const double n = sqrt(dot(rad, rad));
             if (n > 1e-9) low = low + (S.rc / n) * rad;
-            pa = low; pb = mk(low.x, low.y, S.ground_z);
-            d = low.z - S.ground_z; // signed: < 0 = sunk into the ground
-        } else if (j != i) {
-            const Cyl o = {mk(lc[6 * j], lc[6 * j + 1], lc[6 * j + 2]), mk(lc[6 * j + 3], lc[6 * j + 4], lc[6 * j + 5])};
-            const D3 cc = me.c - o.c;
-            if (sqrt(dot(cc, cc)) - 2 * bound > S.max_dist) d = INFINITY;
-            else d = gjk_cyl_cyl(me, o, S.rc, S.hl, pa, pb);
+            put(i, N, low.z - S.ground_z, low, mk(low.x, low.y, S.ground_z)); // signed: < 0 = sunk into the ground
+        } else put(i, i, 0.0, me.c, me.c);
+    }
+    // the pairs i < j, in chunks of the ordered index i * N + j
+    const int total = N * N;
+    for (int base = 0; base < total; base += PROX_CHUNK) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (int idx = base + threadIdx.x; idx < min(base + PROX_CHUNK, total); idx += blockDim.x) {
+            const int i = idx / N, j = idx - i * N;
+            if (i >= j) continue;
+            const D3 ci = mk(lc[6 * i], lc[6 * i + 1], lc[6 * i + 2]), cj = mk(lc[6 * j], lc[6 * j + 1], lc[6 * j + 2]);
+            const D3 cc = ci - cj;
+            if (sqrt(dot(cc, cc)) - 2 * bound > S.max_dist) { put(i, j, INFINITY, ci, ci); put(j, i, INFINITY, cj, cj); }
+            else s_list[atomicAdd(&s_n, 1)] = ((unsigned)i << 16) | (unsigned)j;
         }
-        const size_t o1 = (a0 + i) * (size_t)(N + 1) + j;
-        S.dist[o1] = (float)d;
-        if (S.p_self) { S.p_self[3 * o1] = (float)pa.x; S.p_self[3 * o1 + 1] = (float)pa.y; S.p_self[3 * o1 + 2] = (float)pa.z; }
-        if (S.p_other) { S.p_other[3 * o1] = (float)pb.x; S.p_other[3 * o1 + 1] = (float)pb.y; S.p_other[3 * o1 + 2] = (float)pb.z; }
+        __syncthreads();
+        const int n = s_n;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const int i = (int)(s_list[k] >> 16), j = (int)(s_list[k] & 0xFFFFu);
+            const Cyl me = cyl(i), o = cyl(j);
+            D3 pa = me.c, pb = me.c;
+            const double d = gjk_cyl_cyl(me, o, S.rc, S.hl, pa, pb);
+            put(i, j, d, pa, pb);
+            put(j, i, d, pb, pa);
+        }
+        __syncthreads();
     }
 }
 

@@ -101,7 +101,8 @@ class QuadView:
         with a leading E axis plus a boolean 'valid' (E,) instead of empty results.  body=True returns the points in
         this quadcopter's frame, R^T (p - pos) (what Object.py:129-131 is after; as written it mis-broadcasts)."""
         j = other.uid if not isinstance(other, int) else other
-        dist, ps, po = self.env.proximity(points=True)
+        # pairs further apart than MAX_DIST are culled on their bounding spheres ahead of GJK (they come back as +inf)
+        dist, ps, po = self.env.proximity(max_dist=float(MAX_DIST), points=True)
         sh = self.env._mrs.shard
         b = lambda t: t.unsqueeze(0) if sh.E == 1 else t
         d, a, c = b(dist)[:, self._i, j], b(ps)[:, self._i, j], b(po)[:, self._i, j]
@@ -126,8 +127,8 @@ class QuadView:
         sh = self.env._mrs.shard
         if sh.E != 1:
             return self._contact_points_batched(other, body)
-        dist, ps, po = self.env.proximity(points=True)
         thr = float(sh.params.contact_threshold)
+        dist, ps, po = self.env.proximity(max_dist=thr, points=True)     # only pairs within the threshold go through GJK
         d = dist[self._i].clone()
         d[self._i] = float('inf')
         if other is not None:
@@ -151,8 +152,8 @@ class QuadView:
 
     def _contact_points_batched(self, other, body):
         sh = self.env._mrs.shard
-        dist, ps, po = self.env.proximity(points=True)             # (E,N,N+1), (E,N,N+1,3) x2
         thr = float(sh.params.contact_threshold)
+        dist, ps, po = self.env.proximity(max_dist=thr, points=True)   # (E,N,N+1), (E,N,N+1,3) x2; culled beyond the threshold
         d = dist[:, self._i].clone()                                # (E,N+1)
         d[:, self._i] = float('inf')
         if other is not None:
@@ -184,7 +185,7 @@ class QuadView:
         if sh.E != 1:
             # batched envs: {'object': (E,M) int64 object indices in the one-env form's order (quadcopters ascending, then the
             # ground = N), -1 padded, M = N + 1; 'count': (E,)}
-            dist = self.env.proximity()                                 # (E,N,N+1)
+            dist = self.env.proximity(max_dist=float(radius))           # (E,N,N+1); +inf beyond the radius
             pos = self.env.get_pos()                                    # (E,N,3)
             bound = float((sh.params.coll_radius ** 2 + sh.params.coll_half_len ** 2) ** 0.5)
             me = pos[:, self._i]
@@ -195,7 +196,7 @@ class QuadView:
             order, count = self._padded(keep, None)
             valid = torch.arange(sh.N + 1, device=keep.device)[None, :] < count[:, None]
             return {'object': torch.where(valid, order, torch.full_like(order, -1)), 'count': count}
-        dist = self.env.proximity()
+        dist = self.env.proximity(max_dist=float(radius))
         pos = self.env.get_pos()
         bound = float((sh.params.coll_radius ** 2 + sh.params.coll_half_len ** 2) ** 0.5)
         out = []

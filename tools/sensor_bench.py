@@ -53,6 +53,8 @@ us = timeit(lambda: sh.raycast(off, dirs, body=True, RANGE=5.0), 20)
 line("mrs_raycast  N=64 x4096, 8 rays per agent", us, E * N * (28 + R * 32), "(each ray against 64 cylinders + the ground box)")
 us = timeit(lambda: sh.proximity(points=True), 5)
 line("mrs_proximity N=64 x4096, with points", us, E * N * (28 + (N + 1) * 28), "(4032 GJK pairs per env, float64)")
+us = timeit(lambda: sh.proximity(max_dist=0.02, points=True), 10)
+line("mrs_proximity N=64 x4096, max_dist 0.02, points", us, E * N * (28 + (N + 1) * 28), "(what collisions / get_contact_points ask for)")
 us = timeit(lambda: sh.proximity(max_dist=0.5), 10)
 line("mrs_proximity N=64 x4096, max_dist 0.5", us, E * N * (28 + (N + 1) * 4), "(bounding-sphere cull in front of GJK)")
 act = torch.zeros(E, N, 3, device="cuda:0")
