@@ -676,3 +676,31 @@ def test_quad_contact_kwarg_reaches_the_kernel():
         vx[flag] = env.shard.view(env.shard.vel)[0, :, 0].cpu().numpy()
     assert abs(vx[False][0] - 1.5) < 0.05 and abs(vx[False][1] + 1.5) < 0.05, vx
     assert abs(vx[True][0] - 0.5) < 0.05 and abs(vx[True][1] + 0.5) < 0.05, vx
+
+
+def test_solver_iters_and_rest_shortcut_kwargs_reach_the_kernel():
+    """MRS(..., SOLVER_ITERS=k, REST_SHORTCUT=flag) -> MrsParams.solver_iters / rest_shortcut (include/mrs_hip.h).  Bodies dropped
+    flat onto the ground: with the shortcut they are finished in their own lane once they lie still, without it they keep going
+    through the sweeps -- the two agree to the shortcut's stated 1e-5 m/s per step, and a cap of 1 sweep
+    leaves a tilted touchdown visibly less converged than the default 10."""
+    import mrsgym_amd
+    E, N = 2, 12
+    pos, eul = grid_spawn(E, N, seed=3)
+    pos[..., 2] = 0.53
+    flat = np.zeros_like(eul)
+    out = {}
+    for key, kw, ori in (("on", {}, flat), ("off", dict(REST_SHORTCUT=False), flat), ("k1", dict(SOLVER_ITERS=1), eul * 0 + [0.3, -0.2, 0.5]),
+                         ("k10", {}, eul * 0 + [0.3, -0.2, 0.5])):
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, START_POS=torch.from_numpy(pos), ACTION_TYPE="set_target_vel", **kw)
+        prm = env.shard.params
+        assert int(prm.rest_shortcut) == int(kw.get("REST_SHORTCUT", True)) and int(prm.solver_iters) == int(kw.get("SOLVER_ITERS", 10))
+        env.reset(ori=torch.from_numpy(np.ascontiguousarray(ori, dtype=np.float32)))
+        for _ in range(120):
+            env.step(None)                       # no rotor forces: the bodies fall 1.75 cm and come to rest
+        sh = env.shard
+        out[key] = torch.cat([sh.view(sh.pos), sh.view(sh.vel), sh.view(sh.angvel)], -1).cpu().numpy()
+    assert np.abs(out["on"][..., 2] - 0.5125).max() < 1e-4            # lying on the ground top, hull half-length above it
+    assert np.abs(out["on"] - out["off"]).max() < 1e-4 and np.abs(out["on"][..., 3:]).max() < 1e-4
+    assert np.abs(out["k1"] - out["k10"]).max() > 1e-6                 # the cap does reach the sweeps
+    with pytest.raises(ValueError):
+        mrsgym_amd.make('mrs-v0', N_AGENTS=3, state_fn=state_fn, SOLVER_ITERS=0)

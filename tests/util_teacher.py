@@ -57,7 +57,7 @@ def classify(pre, P, N):
     return ph
 
 
-def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None):
+def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None):
     """Returns dict: err[phase] = array of per-body per-step errors (max over the 13 state words, relative above
     magnitude 1), visited counters, adjacency mismatches (must be 0)."""
     c = CONFIGS[cfg]
@@ -100,6 +100,15 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
         for k, ref in (("pos", sw.pos), ("quat", sw.quat), ("vel", sw.vel), ("angvel", sw.angvel)):
             e = np.maximum(e, (np.abs(post[k] - ref) / np.maximum(1.0, np.abs(ref))).max(-1))
         e = np.where(np.isfinite(e), e, np.inf)
+        if dump is not None:   # diagnostic: the worst contact-phase cases with everything needed to replay them on the host
+            thr = dump.get("thr", 5e-5)
+            for (ee, ii) in zip(*np.nonzero((e > thr) & (ph > 0))):
+                if len(dump.setdefault("cases", [])) < dump.get("max", 400):
+                    dump["cases"].append(dict(t=t, env=int(ee), agent=int(ii), phase=int(ph[ee, ii]), err=float(e[ee, ii]),
+                                              pre=np.concatenate([pre[k][ee, ii] for k in ("pos", "quat", "vel", "angvel")]),
+                                              gpu=np.concatenate([post[k][ee, ii] for k in ("pos", "quat", "vel", "angvel")]),
+                                              orc=np.concatenate([sw.pos[ee, ii], sw.quat[ee, ii], sw.vel[ee, ii], sw.angvel[ee, ii]]),
+                                              wrench=sw.wrench[ee, ii].copy(), action=a[ee, ii].copy()))
         for i, p in enumerate(PHASES):
             m = ph == i
             if m.any():

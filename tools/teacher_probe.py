@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--envs", type=int, default=32)
     ap.add_argument("--configs", default="C2,C3,C4,C5")
     ap.add_argument("--solver-iters", type=int, default=0)
+    ap.add_argument("--dump", default="", help="write the worst contact-phase cases (pre-state, both post-states, wrench) to this .npz")
     a = ap.parse_args()
     print("teacher-forced per-step error |GPU - oracle| (max over the 13 state words, relative above magnitude 1),")
     print("oracle re-seeded from the GPU state every step; E = %d envs, %d steps; phases by the body's pre-step state" % (a.envs, a.steps))
@@ -32,7 +33,8 @@ def main():
             params = mrsgym_amd.default_params()
             params.solver_iters = a.solver_iters
         t0 = time.time()
-        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params,
+        dump = {"thr": 5e-5, "max": 400} if a.dump else None
+        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump,
                    progress=lambda t: print("   ... %s step %d (%.0f s)" % (cfg, t, time.time() - t0), flush=True))
         print("%s  N=%d  %s  solver_iters=%d  grounded at the end %.0f %%  adjacency/observation mismatches %d  visited %s"
               % (cfg, r["N"], ut.CONFIGS[cfg]["atype"], int((params or mrsgym_amd.default_params()).solver_iters),
@@ -42,6 +44,10 @@ def main():
             if q:
                 print("   %-7s n=%9d  50%% %.2e  99%% %.2e  99.9%% %.2e  max %.2e  at (t, env, agent) %s"
                       % (ph, q["n"], q["q50"], q["q99"], q["q999"], q["max"], r["worst"][ph][1]))
+        if dump and dump.get("cases"):
+            import numpy as np
+            c = dump["cases"]
+            np.savez(a.dump.replace(".npz", "_%s.npz" % cfg), **{k: np.array([x[k] for x in c]) for k in c[0]})
         sys.stdout.flush()
 
 
