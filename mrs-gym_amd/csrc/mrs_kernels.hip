@@ -833,15 +833,34 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 // waves keep 3 / 2 / 1 / 0 / 0: N = 256 x 1024 envs 45.8 against 47.2 us with the compressed ladder.
 #ifndef MRS_P_DW1
 #define MRS_P_DW1 3
-#define MRS_P_DW2 3
+#endif
+#ifndef MRS_P_CTRL
 #define MRS_P_CTRL 2
+#endif
+#ifndef MRS_P_FORCE
 #define MRS_P_FORCE 1 // rotor forces, aerodynamics, velocity integration (after the controller)
+#endif
+#ifndef MRS_P_TAIL
 #define MRS_P_TAIL 0
+#endif
+#ifndef MRS_P_ADJ
 #define MRS_P_ADJ 0
-#define MRS_P1_CTRL 3 // N <= 64
-#define MRS_P1_FORCE 2
-#define MRS_P1_TAIL 1
-#define MRS_P1_ADJ 1
+#endif
+// Round 4: with the sweep cap back at 10 the solve is a third longer, and the steep ladder wins for one-wave envs too: 3 / 2 / 1 / 0 / 0
+// against round 3's 3 / 3 / 2 / 1 / 1 over five interleaved rounds of three 400-step windows on two boxes: 22.48 against 22.79 us per
+// step (means; best windows 21.73 against 22.15), 3 / 3 / 2 / 0 / 0: 22.81, 3 / 2 / 2 / 0 / 0: 23.22, 3 / 3 / 1 / 0 / 0: 22.88, 3 / 2 / 1 / 1 / 1: 22.92,
+// 3 / 2 / 0 / 0 / 0: 22.90, 3 / 1 / 1 / 0 / 0: 22.98, 3 / 3 / 3 / 1 / 1: 24.3, 3 / 3 / 2 / 2 / 2: 23.0 (profiles/r04_ab.txt).  The macros stay apart for A/B builds.
+#ifndef MRS_P1_CTRL
+#define MRS_P1_CTRL 2 // N <= 64
+#endif
+#ifndef MRS_P1_FORCE
+#define MRS_P1_FORCE 1
+#endif
+#ifndef MRS_P1_TAIL
+#define MRS_P1_TAIL 0
+#endif
+#ifndef MRS_P1_ADJ
+#define MRS_P1_ADJ 0
 #endif
 // s_setprio takes an immediate: the choice between the two ladders is a (uniform) branch
 #define MRS_SETPRIO(one_wave, p1, pn) do { if (one_wave) __builtin_amdgcn_s_setprio(p1); else __builtin_amdgcn_s_setprio(pn); } while (0)
