@@ -1122,6 +1122,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 const int lane = tid & 63;
                 // tile + lane: neighbour (lane + k) mod 64 at offset k, no wrap; lane << 2 = ds_bpermute byte address of this lane
                 downwash_acc = downwash_ring64<false>(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
+#ifdef MRS_P_DW2 // A/B: the second half of the pair loop one level down
+                    if (FUSED && j == 7) __builtin_amdgcn_s_setprio(MRS_P_DW2);
+#endif
                     if (!late_loads) return;
                     // (the controller memory the outer loop of the cascade wants right after this loop was tried here too,
                     // passes 10..14: no gain, 27.2 against 27.2 us per step, and spills in set_target_pos)
