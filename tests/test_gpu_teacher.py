@@ -54,6 +54,23 @@ def test_teacher_forced_1000_steps_on_the_benchmarked_workload(cfg):
         assert v["pair"] > 0, v
 
 
+@pytest.mark.parametrize("cfg,E,steps", [("X12", 64, 400), ("X100", 12, 300), ("X192", 8, 300)])
+def test_teacher_forced_other_action_types_and_swarm_sizes(cfg, E, steps):
+    """The same per-step comparison for the ACTION_TYPEs BASELINE's configs leave out (set_target_accel, set_target_ori) and the
+    other shapes of the pair loops: N = 12 (21 envs per workgroup), N = 100 (an env over two waves, the LDS ring exchange), N = 192 (three
+    64-agent blocks, COMM_RANGE = inf: ones - eye rows whatever the positions).  Same tolerances as above."""
+    import mrsgym_amd
+    r = ut.run(torch, mrsgym_amd, cfg, E=E, steps=steps)
+    assert r["adj_bad"] == 0
+    for ph in ut.PHASES:
+        x = r["err"][ph]
+        if x.size == 0:
+            continue
+        tol = TOL_FREE if ph == "free" else TOL_CONTACT_MAX
+        assert x.max() <= tol, "%s %s: per-step error %.3e > %.1e at %s; %s" % (cfg, ph, x.max(), tol, r["worst"][ph][1], ut.quantiles(x))
+    assert r["err"]["free"].size > 0 and r["visited"]["listed"] > 0, r["visited"]
+
+
 def test_c2_full_size_properties():
     """BASELINE configs[1] at full size (N=64 x 1024 envs, set_speeds, RETURN_A=False) into its all-grounded steady state:
     (a) 1024 copies of one env stay bitwise identical; (b) quaternions unit, velocities bounded, nobody sunk into the ground;

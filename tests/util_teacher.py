@@ -18,6 +18,11 @@ CONFIGS = {
     "C3": dict(N=64, atype="set_target_vel", comm_range=5.0),
     "C4": dict(N=256, atype="set_control", comm_range=5.0),
     "C5": dict(N=64, atype="set_target_pos", comm_range=5.0),
+    # beyond BASELINE's four: the remaining ACTION_TYPEs and the other code paths of the pair loops (several envs per wave; the ring
+    # of an env that spans waves but is not whole 64-agent blocks; three blocks), same literal spawn, same chaotic inputs
+    "X12": dict(N=12, atype="set_target_accel", comm_range=2.5),
+    "X100": dict(N=100, atype="set_target_ori", comm_range=5.0),
+    "X192": dict(N=192, atype="set_target_vel", comm_range=float("inf")),
 }
 PHASES = ("free", "rest", "listed", "pair")
 
