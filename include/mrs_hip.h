@@ -93,11 +93,13 @@ typedef struct MrsParams {
      * MrsBuffers.pos itself rather than through mrs_set_state* / mrs_spawn* calls mrs_observe or mrs_adjacency afterwards
      * (either refreshes the flags), or the first step after the write may miss a new contact. */
     int32_t pair_contact;
-    /* 1 (default): a body lying flat at rest on the ground -- |R20|, |R21|, |w|, |v_xy| < 1e-6 after the forces of the step -- is
-     * finished in its own lane (contact_at_rest: all four rim points active with the same gap, for which the equal-share start of
-     * the sweeps IS their solution) instead of being listed for the sequential-impulse solve: an exact special case of the same
-     * model, within 1e-5 m/s of what the float32 sweeps return.  0: every body near the ground goes
-     * through the sweeps, as in the oracle (bench.py's `literal` leg).  ABI 5 (was a reserved word). */
+    /* 1 (default): a body lying FLAT on the ground -- |R20|, |R21| < 1e-6: all four rim points active with one common gap -- whose
+     * rows have a closed-form fixed point is finished in its own lane (contact_at_rest) instead of being listed for the
+     * sequential-impulse solve: lifting (no rim point's right-hand side is positive: no impulse at all, exact) or sticking (the
+     * contact can hold it: v = (0, 0, u), w = 0; a conservative yaw-free feasibility test of the normal and friction impulses).
+     * A body at rest is the special case w = 0, v_xy = 0 (round 3).  Within 3e-6 m/s of what 400 float64 sweeps converge to on
+     * 70 000 captured contact problems.  0: every body near the ground goes through the sweeps, as in the
+     * oracle (bench.py's `literal` leg).  ABI 5 (was a reserved word). */
     int32_t rest_shortcut;
 } MrsParams;
 
