@@ -854,7 +854,7 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 #ifndef MRS_REST_EPS
 #define MRS_REST_EPS 1e-6
 #endif
-// Round 4: the same argument does not need the body to be at REST, only FLAT.  For a body lying flat (|R20|, |R21| < eps, all
+// Round 4: the same argument does not need the body to be at REST, only FLAT.  For a body lying flat (|R20|, |R21| < MRS_FLAT_EPS, all
 // four rim points within the threshold with one common gap) with ANY unconstrained velocity (v, w) the rows have two closed-form
 // fixed points, and the sweeps -- whose equal-share start already is most of the way there -- converge to them:
 //   (A) lifting: every rim point's right-hand side rhs_k = (u - v_z) - (w x r_k)_z is <= 0 (u = the common target normal
@@ -874,6 +874,16 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
 // 5 % of C5's, 1 % of C3's -- the bodies whose float32 sweeps used to end 1e-4 ... 2.5e-4 rad/s from the float64 ones
 // (tests/test_gpu_teacher.py) now end at exactly zero.  The margin factor keeps the test strictly inside the pyramid.
 // The rest case above is the special case w = 0, v_xy = 0.  MrsParams.rest_shortcut = 0 sends every body through the sweeps.
+// How flat is flat (MRS_FLAT_EPS): the closed forms ignore the tilt, i.e. the levelling rotation ~ tilt / dt that the rows would
+// give the body, and a body that is finished here every step is never levelled.  Teacher-forced against the oracle (500 steps of
+// C3 / C2 / C4, tools/probes/ab_eps_r4.sh, profiles/r04_ab.txt), error of the bodies lying still before the step, median / 99 %:
+// bound 1e-6 (round 3's, then for bodies at rest only): 4.9e-5 / 8.4e-5; 3e-7: 1.5e-5 / 2.5e-5; 1e-7: 4.9e-6 / 8.6e-6;
+// 3e-8: 1.4e-6 / 2.7e-6 (rest-only shortcut at 1e-6, round 3: 2.2e-6 / 4.3e-6 -- its bodies had been levelled by the sweeps first).
+// The step's duration: C4 45.0 us at every bound against 47.6 rest-only; C3 22.3 at 1e-6 against 22.8 at the tighter bounds and 22.9
+// rest-only -- the half microsecond would have been bought with the levelling of bodies tilted by up to a microradian, and was left.
+#ifndef MRS_FLAT_EPS
+#define MRS_FLAT_EPS 3e-8
+#endif
 MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, const double q[4], double v[3], double w[3])
 {
     const double eps = MRS_REST_EPS;
@@ -882,7 +892,7 @@ MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, con
     const double r20 = 2.0 * (q[0] * q[2] - q[3] * q[1]), r21 = 2.0 * (q[1] * q[2] + q[3] * q[0]);
     const double r22 = 1.0 - 2.0 * (q[0] * q[0] + q[1] * q[1]);
     const double dist = (pz - P.ground_z) - P.coll_half_len * fabs(r22);
-    if (!(fmax(fabs(r20), fabs(r21)) < eps) || !(fabs(dist - P.contact_threshold) > eps)) return false;
+    if (!(fmax(fabs(r20), fabs(r21)) < MRS_FLAT_EPS) || !(fabs(dist - P.contact_threshold) > eps)) return false;
 #ifndef MRS_FLAT_SHORTCUT
 #define MRS_FLAT_SHORTCUT 1 // A/B switch (tools/abl_build.sh): 0 = round 3's form, bodies at rest only
 #endif

@@ -33,7 +33,7 @@ def main():
             params = mrsgym_amd.default_params()
             params.solver_iters = a.solver_iters
         t0 = time.time()
-        dump = {"thr": 5e-5, "max": 400} if a.dump else None
+        dump = {"thr": float(os.environ.get("DUMP_THR", "5e-5")), "max": 400} if a.dump else None
         r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump,
                    progress=lambda t: print("   ... %s step %d (%.0f s)" % (cfg, t, time.time() - t0), flush=True))
         print("%s  N=%d  %s  solver_iters=%d  grounded at the end %.0f %%  adjacency/observation mismatches %d  visited %s"
