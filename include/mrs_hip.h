@@ -93,7 +93,7 @@ typedef struct MrsParams {
      * MrsBuffers.pos itself rather than through mrs_set_state* / mrs_spawn* calls mrs_observe or mrs_adjacency afterwards
      * (either refreshes the flags), or the first step after the write may miss a new contact. */
     int32_t pair_contact;
-    /* 1 (default): a body lying FLAT on the ground -- |R20|, |R21| < 3e-8: all four rim points active with one common gap -- whose
+    /* 1 (default): a body lying FLAT on the ground -- |R20|, |R21| < 1e-6: all four rim points active with one common gap -- whose
      * rows have a closed-form fixed point is finished in its own lane (contact_at_rest) instead of being listed for the
      * sequential-impulse solve: lifting (no rim point's right-hand side is positive: no impulse at all, exact) or sticking (the
      * contact can hold it: v = (0, 0, u), w = 0; a conservative yaw-free feasibility test of the normal and friction impulses).

@@ -43,7 +43,7 @@ class OrcParams(C.Structure):
         ("use_gyro", C.c_int),
         ("ground_z", C.c_double), ("friction", C.c_double), ("erp", C.c_double),
         ("contact_threshold", C.c_double),
-        ("solver_iters", C.c_int), ("enable_contact", C.c_int), ("pair_contact", C.c_int),
+        ("solver_iters", C.c_int), ("enable_contact", C.c_int), ("pair_contact", C.c_int), ("rest_shortcut", C.c_int),
     ]
 
 
@@ -106,6 +106,7 @@ def lib():
         _lib.orc_raycast.argtypes = [PP, C.c_int, dp, dp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_float, ip, fp, fp, fp]
         _lib.orc_closest.argtypes = [PP, C.c_int, dp, dp, C.c_int, dp, dp, dp]
         _lib.orc_proximity.argtypes = [PP, C.c_int, dp, dp, dp]
+        _lib.orc_contact_rows.argtypes = [PP, dp, dp, dp, dp, C.c_int]
         _lib.orc_spawn_from.argtypes = [C.c_int, C.c_int, fp, C.c_double, fp]
         _lib.orc_spawn_from.restype = C.c_int
     return _lib
@@ -271,6 +272,13 @@ def proximity(pos, quat, params=None):
     D = np.zeros((N, N + 1))
     lib().orc_proximity(C.byref(p), N, _d(pos), _d(quat), _d(D))
     return D
+
+
+def contact_rows(params, pos, quat, v, w, n_sweeps):
+    """The ground-contact rows of one body swept n_sweeps times without closed forms or early exits: returns (v, w) after."""
+    v, w = f64(v).copy(), f64(w).copy()
+    lib().orc_contact_rows(C.byref(params), _d(f64(pos)), _d(f64(quat)), _d(v), _d(w), int(n_sweeps))
+    return v, w
 
 
 def spawn_from(cand, agent_radius=0.3):

@@ -56,6 +56,7 @@ typedef struct OrcParams {
     int solver_iters;
     int enable_contact;
     int pair_contact;    /* quad-quad contact as a sphere separation constraint (mrs_oracle.c:pair_contact) */
+    int rest_shortcut;   /* flat bodies whose contact rows have a closed-form fixed point get it (contact_flat_closed_form); 0: sweeps only */
 } OrcParams;
 
 /* Per-agent controller memory (QuadControl.py lazily-created attributes). */
@@ -133,6 +134,10 @@ void orc_step_full(const OrcParams *p, int E, int N, double *pos, double *quat, 
  * them by tools/gen_golden.py (fake-bullet harness) and for unit tests. */
 void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel[3], double angvel[3],
                    const double force_body[3], const double torque_body[3]);
+
+/* test hook: the ground-contact rows of ONE body swept n_sweeps times, no closed forms, no early exits (v, w in/out: the
+ * unconstrained velocities -> the constrained ones) */
+void orc_contact_rows(const OrcParams *p, const double pos[3], const double quat[4], double v[3], double w[3], int n_sweeps);
 
 /* ---- geometry sensors (mrs_sensors.c; Object.py:100-174 against the analytic scene; PARITY UNPINNED, see there) ---- */
 /* Object.raycast (Object.py:150-174) for agent `self` of ONE env: hit_obj -1 none / 0..N-1 quadcopter / N ground */

@@ -44,7 +44,7 @@ def test_params_struct_layout_and_constants():
     import oracle
     o = oracle.default_params()
     for name, _ in native.MrsParams._fields_:
-        if name in ("round_euler_readback", "rest_shortcut"):   # product-only switch (the oracle always rounds, like the reference)
+        if name == "round_euler_readback":   # product-only switch (the oracle always rounds, like the reference)
             continue
         a, b = getattr(p, name), getattr(o, name)
         if hasattr(a, "__len__"):
