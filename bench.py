@@ -309,7 +309,9 @@ def main():
                      "every fidelity knob at its literal setting: 10 contact sweeps, the controller's float32 rounding of the Euler "
                      "read-back (Object.py:97 -> QuadControl.py:99), every grounded body through the sweeps (no at-rest shortcut)"),
                     ("solver6", dict(SOLVER_ITERS=6),
-                     "library defaults except a cap of 6 contact sweeps (round 3's headline setting; accuracy: tests/golden/F6c)")):
+                     "library defaults except a cap of 6 contact sweeps (round 3's headline setting; accuracy: tests/golden/F6c)")) + (
+                    (("default_again", dict(), "diagnostic (MRS_BENCH_REPEAT_DEFAULT=1): the library defaults once more, as the last leg"),)
+                    if os.environ.get("MRS_BENCH_REPEAT_DEFAULT") == "1" else ()):
                 lenv = make_env("packed", **knobs)
                 warm(min(prewarm_s, 0.3))
                 rollin(lenv)
