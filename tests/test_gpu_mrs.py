@@ -598,7 +598,7 @@ def test_bench_contract_single_and_two_ranks():
     assert (m["solver_iters"], m["round_euler_readback"], m["rest_shortcut"], m["pair_contact"]) == (10, 0, 1, 1)
     assert d["literal"]["model"]["round_euler_readback"] == 1 and d["literal"]["model"]["rest_shortcut"] == 0 and d["literal"]["model"]["solver_iters"] == 10
     assert d["solver6"]["model"]["solver_iters"] == 6 and d["literal"]["kernel_ms"] > 0 and 0 < d["solver6"]["roofline_frac"] < 1
-    env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo")
+    env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo", MRS_BENCH_DIRECT="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
                           "--gpus", "2"] + common, env=env2, capture_output=True, text=True, timeout=600)
