@@ -307,7 +307,7 @@ def main():
             for key, knobs, what in (
                     ("literal", dict(SOLVER_ITERS=10, ROUND_EULER_READBACK=True, REST_SHORTCUT=False),
                      "every fidelity knob at its literal setting: 10 contact sweeps, the controller's float32 rounding of the Euler "
-                     "read-back (Object.py:97 -> QuadControl.py:99), every grounded body through the sweeps (no at-rest shortcut)"),
+                     "read-back (Object.py:97 -> QuadControl.py:99), every body near the ground through the sweeps (no closed forms for flat bodies)"),
                     ("solver6", dict(SOLVER_ITERS=6),
                      "library defaults except a cap of 6 contact sweeps (round 3's headline setting; accuracy: tests/golden/F6c)")) + (
                     (("default_again", dict(), "diagnostic (MRS_BENCH_REPEAT_DEFAULT=1): the library defaults once more, as the last leg"),)
