@@ -318,7 +318,7 @@ def main():
                 l_elapsed, _, l_kernel_ms = timed_region(lenv, args.rollin, False)
                 l_ach = ALGO_BYTES_PER_AGENT_STEP * E * N / (l_kernel_ms * 1e-3) / 1e9
                 extra[key] = {"value": agent_steps / l_elapsed, "unit": "agent-steps/s", "ms_per_step": l_elapsed / args.steps * 1e3,
-                              "kernel_ms": l_kernel_ms, "roofline_frac": l_ach / HBM_PEAK_GBS, "model": model_of(lenv), "what": what}
+                              "kernel_ms": l_kernel_ms, "roofline_frac": l_ach / HBM_PEAK_GBS, "fidelity": model_of(lenv), "what": what}
                 del lenv
         if args.double_buffer and E % 2 == 0:
             # BESIDE `value`, never instead of it: the same swarm as two half-swarms on two streams, each stepping on its own
@@ -431,7 +431,7 @@ def main():
                                                                              ", joint observation all-gathered every step" if world > 1 else ""),
                    "n_agents": N, "n_envs_per_gpu": E, "k_hops": K_HOPS, "comm_range": COMM_RANGE,
                    # the product's fidelity knobs as `value` was measured (the library's defaults; `literal` / `solver6` beside it)
-                   "model": model,
+                   "fidelity": model,
                    "parallelism": "env-sharded x%d, RCCL all-gather of the newest observation slice per step" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,

@@ -594,10 +594,10 @@ def test_bench_contract_single_and_two_ranks():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["config"]["workload"]
     assert d["rollin_steps"] == 700 and d["dense_a"]["value"] > 0 and d["dense_a"]["ms_per_step"] > 0
     # the fidelity knobs `value` was measured with (the library's defaults) and the two legs beside it
-    m = d["config"]["model"]
+    m = d["config"]["fidelity"]
     assert (m["solver_iters"], m["round_euler_readback"], m["rest_shortcut"], m["pair_contact"]) == (10, 0, 1, 1)
-    assert d["literal"]["model"]["round_euler_readback"] == 1 and d["literal"]["model"]["rest_shortcut"] == 0 and d["literal"]["model"]["solver_iters"] == 10
-    assert d["solver6"]["model"]["solver_iters"] == 6 and d["literal"]["kernel_ms"] > 0 and 0 < d["solver6"]["roofline_frac"] < 1
+    assert d["literal"]["fidelity"]["round_euler_readback"] == 1 and d["literal"]["fidelity"]["rest_shortcut"] == 0 and d["literal"]["fidelity"]["solver_iters"] == 10
+    assert d["solver6"]["fidelity"]["solver_iters"] == 6 and d["literal"]["kernel_ms"] > 0 and 0 < d["solver6"]["roofline_frac"] < 1
     env2 = dict(env, MRS_BENCH_SINGLE_DEVICE="1", MRS_DIST_BACKEND="gloo", MRS_BENCH_DIRECT="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
