@@ -575,9 +575,13 @@ static int contact_flat_closed_form(const OrcParams *p, const double pos[3], con
 
 static void contact_solve_ex(const OrcParams *p, const double pos[3], const double R[9], double v[3], double w[3], int n_sweeps, int early_exit,
                              int closed_forms);
+/* diagnostic hook (tools/teacher_replay.py): n > 0 = every solve runs exactly n sweeps, no early exit; 0 = the model's rule */
+static int g_force_sweeps = 0;
+void orc_debug_force_sweeps(int n) { g_force_sweeps = n; }
 static void contact_solve(const OrcParams *p, const double pos[3], const double R[9], double v[3], double w[3])
 {
-    contact_solve_ex(p, pos, R, v, w, p->solver_iters, 1, p->rest_shortcut);
+    if (g_force_sweeps > 0) contact_solve_ex(p, pos, R, v, w, g_force_sweeps, 0, p->rest_shortcut);
+    else contact_solve_ex(p, pos, R, v, w, p->solver_iters, 1, p->rest_shortcut);
 }
 /* test hook: the twelve rows of one body swept n_sweeps times with neither the closed forms nor the early exits -- what the
  * closed forms and the capped sweeps are measured against (tests/test_oracle_physics.py) */

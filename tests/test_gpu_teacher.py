@@ -6,14 +6,17 @@ controller memory) every step.  Per step and body, |delta| relative above magnit
   * free flight: <= 2e-5 (measured: 8e-6 worst of 9.8 million body-steps, median 1e-8 ... 4e-8);
   * bodies in ground contact (lying still, or in the sequential-impulse sweeps) or in quad-quad contact: median <= 5e-6,
     99 % <= 2e-4, worst <= 5e-4 (measured: 99 % 2e-5 for the listed bodies, 1.6e-4 for the few hundred in pair contact, worst
-    3.4e-4).  VERDICT r3 asked for 1e-4 here.  What is above it (0.1 % of the body-steps in contact) was looked at case by case
-    (tools/teacher_probe.py --dump): the word is always the ANGULAR VELOCITY, nearly always of a body lying flat on the ground
-    under rotor thrust, where the float64 sweeps end at |w| ~ 0 and the float32 ones at 1e-4 ... 2.5e-4 rad/s -- the sweeps stop
-    on a discontinuous rule (no progress: a pair of sweeps moved the impulses by at least half of what the pair before did),
-    which the two precisions take one pair of sweeps apart in borderline cases, and the residual at that point is of that
-    size.  It is not the sweep cap (with 50 sweeps the same tail, profiles/r04_teacher_forced.txt) and not the conditioning of
-    the step (the oracle against itself on inputs perturbed by half a float32 ulp: 7e-6 worst); 1e-4 rad/s is 1e-6 rad per
-    step, and either solve is itself 9e-4 (99 %) from the converged one (tests/golden/F6c);
+    3.4e-4).  VERDICT r3 asked for 1e-4 here.  What is above it (0.1 % of the body-steps in contact) is FLOAT32 RESOLUTION OF LARGE
+    VELOCITIES, not a defect of the solve: the word is the angular velocity, and the body is one whose unconstrained velocity --
+    what the contact solve is handed and has to cancel -- sits at or near Bullet's clamp of 100 m/s (the reference's ground-effect
+    term is singular at the ground, Quadcopter.py:87-96: a body lying on it is driven to the clamp every step; and crashed bodies
+    of the PID modes travel at 90 m/s).  float32 resolves 100 m/s to 7.6e-6 m/s, and at the levers of the rim points (0.0125 ...
+    0.06 m) that is 1e-4 ... 6e-4 rad/s.  Evidence (tools/teacher_probe.py --dump, tools/teacher_replay.py, tools/host_f32/, round 4,
+    617 dumped cases above 2e-5): the kernel's own contact function compiled for the CPU reproduces the GPU's result to 1e-7; THE
+    SAME STATEMENTS instantiated in float64 reproduce the oracle to 1e-12; no case is a stopping decision taken differently (the
+    oracle forced to every other sweep count is never closer to the GPU: round 4 first read the tail that way, wrongly); set-up
+    and sweeps contribute alike; 88 % / 35 % / 78 % of the cases (C2 / C3 / C5) have an unconstrained velocity above 50 m/s, and
+    among the contact body-steps whose unconstrained velocity is below 5 m/s the worst error is 3.2e-5 -- asserted below at 5e-5;
   * adjacency rows and the observation slice bit-exact every step;
 and the run must have visited touchdown, rest, tumbling on the ground and pair contact.
 Per-phase error quantiles of the same runs: tools/teacher_probe.py -> profiles/r04_teacher_forced.txt.
@@ -26,14 +29,14 @@ import util_teacher as ut
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-TOL_FREE, TOL_CONTACT_MAX, TOL_CONTACT_99, TOL_CONTACT_MEDIAN = 2e-5, 5e-4, 2e-4, 5e-6
+TOL_FREE, TOL_CONTACT_MAX, TOL_CONTACT_99, TOL_CONTACT_MEDIAN, TOL_CONTACT_ORDINARY = 2e-5, 5e-4, 2e-4, 5e-6, 5e-5
 
 
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_teacher_forced_1000_steps_on_the_benchmarked_workload(cfg):
     import mrsgym_amd
     E = 32
-    r = ut.run(torch, mrsgym_amd, cfg, E=E, steps=1000)
+    r = ut.run(torch, mrsgym_amd, cfg, E=E, steps=1000, unconstrained=True)
     assert r["adj_bad"] == 0, "adjacency rows / observation slice differ from the oracle's on the same positions"
     for ph in ut.PHASES:
         x = r["err"][ph]
@@ -44,6 +47,11 @@ def test_teacher_forced_1000_steps_on_the_benchmarked_workload(cfg):
         if ph != "free":
             q = ut.quantiles(x)
             assert q["q99"] <= TOL_CONTACT_99 and q["q50"] <= TOL_CONTACT_MEDIAN, (cfg, ph, q)
+            # where the contact solve is handed velocities of ordinary size, float32 sweeps and float64 sweeps agree to 5e-5:
+            # everything above is the float32 resolution of a velocity near the 100 m/s clamp (module text)
+            ordinary = r["vunc"][ph] < 5.0
+            if ph != "pair" and ordinary.any():          # pair contact: the partner's velocity enters too
+                assert x[ordinary].max() <= TOL_CONTACT_ORDINARY, (cfg, ph, float(x[ordinary].max()), int(ordinary.sum()))
     v = r["visited"]
     assert r["err"]["free"].size > 0
     # the workload did go where the benchmark goes: bodies came down, some lay still, some tumbled, some touched each other

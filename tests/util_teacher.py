@@ -62,9 +62,11 @@ def classify(pre, P, N):
     return ph
 
 
-def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None):
+def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None, unconstrained=False):
     """Returns dict: err[phase] = array of per-body per-step errors (max over the 13 state words, relative above
-    magnitude 1), visited counters, adjacency mismatches (must be 0)."""
+    magnitude 1), visited counters, adjacency mismatches (must be 0).  unconstrained=True: the oracle takes every step a
+    second time with both contact models off, and vunc[phase] holds, aligned with err[phase], the largest velocity word
+    (m/s) the contact solve was handed -- what it has to cancel in float32 on the GPU."""
     c = CONFIGS[cfg]
     N, atype, R = c["N"], c["atype"], c["comm_range"]
     pos, eul = grid_spawn(E, N, seed=seed)                      # 1 m pitch, |yaw| <= pi/2: the literal spawn
@@ -86,6 +88,7 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
         return {k: sh.view(getattr(sh, k)).cpu().numpy() for k in ("pos", "quat", "vel", "angvel")}
 
     errs = {p: [] for p in PHASES}
+    vuncs = {p: [] for p in PHASES}
     worst = {p: (0.0, None) for p in PHASES}
     visited = dict(touchdown=0, rest=0, tumbling=0, pair=0, listed=0, nnls=0)
     adj_bad = 0
@@ -101,6 +104,17 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
         pid_to_oracle(pid, sw.pid)
         sw.step(a, atype)
         ph = classify(pre, P, N)
+        if unconstrained:
+            keep = {k: getattr(sw, k).copy() for k in ("pos", "quat", "vel", "angvel")}
+            sw.pos[...] = pre["pos"]; sw.quat[...] = pre["quat"]; sw.vel[...] = pre["vel"]; sw.angvel[...] = pre["angvel"]
+            pid_to_oracle(pid, sw.pid)
+            flags = (sw.p.enable_contact, sw.p.pair_contact)
+            sw.p.enable_contact, sw.p.pair_contact = 0, 0
+            sw.step(a, atype)
+            sw.p.enable_contact, sw.p.pair_contact = flags
+            vu = np.abs(sw.vel).max(-1)
+            for k, v in keep.items():
+                getattr(sw, k)[...] = v
         e = np.zeros((E, N))
         for k, ref in (("pos", sw.pos), ("quat", sw.quat), ("vel", sw.vel), ("angvel", sw.angvel)):
             e = np.maximum(e, (np.abs(post[k] - ref) / np.maximum(1.0, np.abs(ref))).max(-1))
@@ -118,6 +132,8 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
             m = ph == i
             if m.any():
                 errs[p].append(e[m])
+                if unconstrained:
+                    vuncs[p].append(vu[m])
                 j = np.argmax(np.where(m, e, -1))
                 if e.flat[j] > worst[p][0]:
                     worst[p] = (float(e.flat[j]), (t, int(j // N), int(j % N)))
@@ -140,6 +156,7 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
             progress(t + 1)
     out = dict(cfg=cfg, E=E, N=N, steps=steps, visited=visited, adj_bad=adj_bad, worst=worst,
                err={p: (np.concatenate(errs[p]) if errs[p] else np.zeros(0)) for p in PHASES},
+               vunc={p: (np.concatenate(vuncs[p]) if vuncs[p] else np.zeros(0)) for p in PHASES},
                grounded_share=float((pre["pos"][..., 2] < 0.6).mean()))
     return out
 

@@ -81,7 +81,7 @@ def rows_per_point(P):
     return None
 
 
-def pgs12(P, iters, start="equal", order="point", tol=1e-7, stag=0.5, check_every=2, ret_hist=False):
+def pgs12(P, iters, start="equal", order="point", tol=1e-7, stag=0.5, check_every=2, ret_hist=False, vel_tol=None, vel_abs=None):
     """The shipped model (oracle/mrs_oracle.c contact_solve): 4 points x (normal, friction x, friction y)."""
     M = P.M
     dv = np.zeros((M, 3)); dw = np.zeros((M, 3))
@@ -113,6 +113,8 @@ def pgs12(P, iters, start="equal", order="point", tol=1e-7, stag=0.5, check_ever
     for it in range(iters):
         if it % check_every == 0:
             moved = np.zeros(M)
+        if vel_tol is not None and it % check_every == check_every - 1:
+            dv_before, dw_before = dv.copy(), dw.copy()          # the velocity rule looks at what the pair's second sweep changed
         live = ~done
         for k in range(4):
             rk = r[:, k]
@@ -134,9 +136,19 @@ def pgs12(P, iters, start="equal", order="point", tol=1e-7, stag=0.5, check_ever
             hist.append((dv.copy(), dw.copy()))
         if it % check_every == check_every - 1:
             lmax = ln.max(1)
-            conv = moved <= np.maximum(tolv, tol * lmax)
-            stg = moved >= stag * prev
-            done |= conv | stg
+            if vel_tol is not None:     # stop on the body's VELOCITY change (m/s; rotation at the rim) instead of the impulses'
+                dvel = np.maximum(np.abs(dv - dv_before).max(1), P.r * np.abs(dw - dw_before).max(1))
+                scale = np.maximum(P.g * P.dt, np.maximum(np.abs(dv).max(1), P.r * np.abs(dw).max(1)))
+                if vel_abs is not None:   # absolute on every velocity word (m/s, rad/s) + relative to the word sizes of the solve's change
+                    dvel = np.maximum(np.abs(dv - dv_before).max(1), np.abs(dw - dw_before).max(1))
+                    scale = vel_abs + vel_tol * np.maximum(np.abs(dv).max(1), np.abs(dw).max(1))
+                    done |= dvel <= scale
+                else:
+                    done |= dvel <= vel_tol * scale
+            else:
+                conv = moved <= np.maximum(tolv, tol * lmax)
+                stg = moved >= stag * prev
+                done |= conv | stg
             prev = moved.copy()
     return dv, dw, used, (ln, lt), hist
 
@@ -169,6 +181,41 @@ def study():
     dv, dw, used, _, _ = pgs12(P, 10, start="cold")
     report("cold start, <=10", used, dv, dw, ref)
     return P, ref
+
+
+def flip_study():
+    """What a stopping decision that falls the other way costs (float32 sweeps against float64 ones decide differently now and
+    then): per body, the distance between its result at the sweep count the rule stops it at and the result one pair of sweeps
+    later.  The impulse rules (tolerance + stagnation) against a rule on the body's velocity change."""
+    d = np.load(OUT)
+    P = Prob(d)
+    d = d[P.act.any(1)]
+    P = Prob(d)
+    ref = pgs12(P, 400, tol=0, stag=2.0)[:2]
+    hist = pgs12(P, 14, tol=0, stag=2.0, ret_hist=True)[4]        # every body's iterate after 1..14 sweeps (no stopping)
+    def consequence(used):
+        idx = np.arange(P.M)
+        a = np.stack([h[0] for h in hist]); b = np.stack([h[1] for h in hist])      # (14, M, 3)
+        at = lambda k: (a[k - 1, idx], b[k - 1, idx])
+        v0, w0 = at(used); v1, w1 = at(np.minimum(used + 2, 14))
+        return np.maximum(np.abs(v1 - v0).max(1), np.abs(w1 - w0).max(1))
+    for name, kw in (("shipped: impulse tol 1e-7 + stagnation .5", {}), ("impulse tol only (no stagnation rule)", dict(stag=2.0)),
+                     ("velocity rule 1e-6", dict(vel_tol=1e-6)), ("velocity rule 1e-5", dict(vel_tol=1e-5)), ("velocity rule 1e-4", dict(vel_tol=1e-4)),
+                     ("abs 1e-6 + 1e-6 |dv,dw|", dict(vel_tol=1e-6, vel_abs=1e-6)), ("abs 1e-5 + 1e-6 |dv,dw|", dict(vel_tol=1e-6, vel_abs=1e-5)),
+                     ("abs 1e-6 + 1e-5 |dv,dw|", dict(vel_tol=1e-5, vel_abs=1e-6)), ("abs 1e-5 + 1e-5 |dv,dw|", dict(vel_tol=1e-5, vel_abs=1e-5))):
+        dv, dw, used, _, _ = pgs12(P, 10, **kw)
+        report(name, used, dv, dw, ref)
+        c = consequence(used)
+        early = used < 10
+        print("    a flipped decision moves the result (max over v, w) by: median %.1e  99%% %.1e  max %.1e   (bodies stopped before the cap: %d of %d; "
+              "moved by more than 1e-5 / 1e-4 / 1e-3: %d / %d / %d)"
+              % (np.median(c[early]), np.quantile(c[early], 0.99), c[early].max(), early.sum(), P.M, (c[early] > 1e-5).sum(), (c[early] > 1e-4).sum(),
+                 (c[early] > 1e-3).sum()))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "flip":
+    flip_study()
+    sys.exit(0)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def main():
             params.solver_iters = a.solver_iters
         t0 = time.time()
         dump = {"thr": float(os.environ.get("DUMP_THR", "5e-5")), "max": 400} if a.dump else None
-        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump,
+        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump, unconstrained=True,
                    progress=lambda t: print("   ... %s step %d (%.0f s)" % (cfg, t, time.time() - t0), flush=True))
         print("%s  N=%d  %s  solver_iters=%d  grounded at the end %.0f %%  adjacency/observation mismatches %d  visited %s"
               % (cfg, r["N"], ut.CONFIGS[cfg]["atype"], int((params or mrsgym_amd.default_params()).solver_iters),
@@ -44,6 +44,13 @@ def main():
             if q:
                 print("   %-7s n=%9d  50%% %.2e  99%% %.2e  99.9%% %.2e  max %.2e  at (t, env, agent) %s"
                       % (ph, q["n"], q["q50"], q["q99"], q["q999"], q["max"], r["worst"][ph][1]))
+                if ph != "free":        # split by what the contact solve was handed (the oracle's unconstrained velocity, largest word)
+                    import numpy as np
+                    x, vu = r["err"][ph], r["vunc"][ph]
+                    for lo, hi in ((0, 5), (5, 50), (50, 1e9)):
+                        m = (vu >= lo) & (vu < hi)
+                        if m.any():
+                            print("             unconstrained velocity in [%g, %g) m/s: n=%9d  99.9%% %.2e  max %.2e" % (lo, min(hi, 100), m.sum(), np.quantile(x[m], 0.999), x[m].max()))
         if dump and dump.get("cases"):
             import numpy as np
             c = dump["cases"]
