@@ -8,9 +8,10 @@ controller memory) every step.  Per step and body, |delta| relative above magnit
     99 % <= 2e-4, worst <= 5e-4 (measured: 99 % 2e-5 for the listed bodies, 1.6e-4 for the few hundred in pair contact, worst
     3.4e-4).  VERDICT r3 asked for 1e-4 here.  What is above it (0.1 % of the body-steps in contact) is FLOAT32 RESOLUTION OF LARGE
     VELOCITIES, not a defect of the solve: the word is the angular velocity, and the body is one whose unconstrained velocity --
-    what the contact solve is handed and has to cancel -- sits at or near Bullet's clamp of 100 m/s (the reference's ground-effect
-    term is singular at the ground, Quadcopter.py:87-96: a body lying on it is driven to the clamp every step; and crashed bodies
-    of the PID modes travel at 90 m/s).  float32 resolves 100 m/s to 7.6e-6 m/s, and at the levers of the rim points (0.0125 ...
+    what the contact solve is handed and has to cancel -- sits at or near Bullet's clamp of 100 m/s (the reference's downwash
+    term is singular in the height difference, Quadcopter.py:106-109, alpha ~ 1 / dz^2 for every dz > 0: of two bodies lying on the
+    ground within ~0.7 m of each other, float32 heights one ulp apart, the lower is pushed down with 1e2 ... 1e7 N and sits at the
+    clamp after every velocity integration; and crashed bodies of the PID modes travel at 90 m/s).  float32 resolves 100 m/s to 7.6e-6 m/s, and at the levers of the rim points (0.0125 ...
     0.06 m) that is 1e-4 ... 6e-4 rad/s.  Evidence (tools/teacher_probe.py --dump, tools/teacher_replay.py, tools/host_f32/, round 4,
     617 dumped cases above 2e-5): the kernel's own contact function compiled for the CPU reproduces the GPU's result to 1e-7; THE
     SAME STATEMENTS instantiated in float64 reproduce the oracle to 1e-12; no case is a stopping decision taken differently (the

@@ -47,6 +47,13 @@ wgs = [np.where(wg == w)[0] for w in range(E // WPW)]
 key = xcc * 100000 + se * 10000 + shid * 1000 + cu * 10 + simd
 simds = [np.where(key == k)[0] for k in np.unique(key)]
 cus = [np.where(key // 10 == k)[0] for k in np.unique(key // 10)]
+# where the workgroups' FIRST waves sit (wave 0 runs the contact solve of its workgroup: four of them on one SIMD share its issue slots)
+w0 = np.arange(E) % WPW == 0
+per_simd = np.array([int(w0[g].sum()) for g in simds])
+print("first waves of the workgroups: SIMD id histogram %s; first waves per SIMD: %s (count of SIMDs holding 0, 1, 2, ... of them)" % (
+    np.bincount(simd[w0], minlength=4), np.bincount(per_simd)))
+for j in range(WPW):
+    print("   wave %d of its workgroup sits on SIMD: %s" % (j, np.bincount(simd[np.arange(E) % WPW == j], minlength=4)))
 print("waves per SIMD: min %d max %d; per CU: min %d max %d" % (min(map(len, simds)), max(map(len, simds)), min(map(len, cus)), max(map(len, cus))))
 for k in (1, 2, 3, 5, 8):
     print("  spread of '%s' end: within a workgroup %.2f us (mean), within a SIMD %.2f, within a CU %.2f, whole grid %.2f" % (
