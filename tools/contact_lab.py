@@ -739,3 +739,62 @@ def table():
 
 if len(sys.argv) > 1 and sys.argv[1] == "table":
     table()
+
+
+def ls_study():
+    """Bodies standing on all four rim points with friction holding ("sticking"): the rows then ask every rim point for the velocity
+    (0, 0, u_k) -- twelve equations, six unknowns -- and what the sweeps converge to (over hundreds of sweeps; the impulses keep
+    drifting in their null space) is the LEAST-SQUARES velocity, which has a closed form because the four points are symmetric
+    about the cap's centre:  v_centre = (0, 0, mean u),  w_body = diag(1/4c^2, 1/4c^2, 1/8c^2) (sum_k u_k s_k) x z_body.
+    How many of the listed bodies is that, and how do the capped sweeps compare with it?"""
+    d = np.load(OUT)
+    P = Prob(d)
+    d = d[P.act.any(1)]
+    P = Prob(d)
+    M = P.M
+    four = P.act.all(1)
+    c = P.r * 0.70710678118654752440
+    R = P.R
+    sg = np.where(R[:, 2, 2] >= 0, -1.0, 1.0)
+    u = -P.dist * np.where(P.dist > 0, 1 / P.dt, P.erp / P.dt)                     # target normal velocity per point
+    sb = np.array([[c if not (k & 1) else -c, c if not (k & 2) else -c, 0.0] for k in range(4)])    # s_k in the body frame
+    zb = R[:, 2, :]                                                                # world z in body coordinates
+    S = np.einsum("mk,kj->mj", u, sb)
+    wb = np.cross(S, zb) * np.array([1 / (4 * c * c), 1 / (4 * c * c), 1 / (8 * c * c)])
+    w_ls = np.einsum("mij,mj->mi", R, wb)
+    rbar = np.einsum("mij,mj->mi", R, np.stack([np.zeros(M), np.zeros(M), sg * P.hl], -1))
+    v_ls = np.stack([np.zeros(M), np.zeros(M), u.mean(1)], -1) - np.cross(w_ls, rbar)
+    # impulse the body needs for it, and a sufficient test that four contact forces inside their friction pyramids can deliver it
+    lx, lz = 2 * (P.r + 0.002), 2 * (P.hl + 0.002)
+    I0 = P.mass / 12.0 * (lx * lx + lz * lz); I2 = P.mass / 12.0 * (2 * lx * lx)
+    Ib = np.array([I0, I0, I2])
+    dP = P.mass * (v_ls - P.v)
+    dLb = Ib * np.einsum("mji,mj->mi", R, (w_ls - P.w))
+    dL = np.einsum("mij,mj->mi", R, dLb)
+    Mc = dL - np.cross(rbar, dP)                                                   # moment about the cap centre
+    fm = 0.25 * np.maximum(np.abs(dP[:, 0]), np.abs(dP[:, 1])) + np.abs(Mc[:, 2]) * (0.25 / P.r)
+    s = 2 * P.r * (0.25 * dP[:, 2] - fm / P.mu)
+    ok = four & (s > 0) & ((Mc[:, 0] ** 2 + Mc[:, 1] ** 2) * 1.05 < s * s)
+    ref = pgs12(P, 400, tol=0, stag=2.0)[:2]
+    dv10, dw10, used, _, _ = pgs12(P, 10)
+    tilt = np.hypot(R[:, 2, 0], R[:, 2, 1])
+    print("%d listed bodies; all four points active: %d; of those the sufficient test passes: %d" % (M, four.sum(), ok.sum()))
+    e_ls = np.maximum(np.abs(v_ls - (P.v + ref[0])).max(1), np.abs(w_ls - (P.w + ref[1])).max(1))
+    e_10 = np.maximum(np.abs(dv10 - ref[0]).max(1), np.abs(dw10 - ref[1]).max(1))
+    q = lambda x: "median %.1e  99%% %.1e  max %.1e" % (np.median(x), np.quantile(x, 0.99), x.max()) if len(x) else "-"
+    print("  closed form against 400 sweeps, bodies that pass:   " + q(e_ls[ok]))
+    print("  capped sweeps (10) against 400 sweeps, same bodies:  " + q(e_10[ok]))
+    print("  tilt of the bodies that pass: " + q(tilt[ok]))
+    print("  sweeps used now, bodies that pass:   %s" % dict(zip(*np.unique(used[ok], return_counts=True))))
+    print("  sweeps used now, bodies that remain: %s" % dict(zip(*np.unique(used[~ok], return_counts=True))))
+    print("  four points active but the test fails: %d; their closed-form error: %s" % ((four & ~ok).sum(), q(e_ls[four & ~ok])))
+    rng = np.random.default_rng(0)
+    for name, m in (("now", np.ones(M, bool)), ("with the closed form", ~ok)):
+        # solver waves of 5 listed bodies (a workgroup's share at the bench size): the sweeps the wave runs = its slowest body's
+        idx = rng.permutation(np.where(m)[0]); k = int(5 * m.mean() + 0.5) or 1
+        groups = [used[idx[i:i + k]].max() for i in range(0, len(idx) - k + 1, k)]
+        print("  %-22s listed per workgroup %.1f -> sweeps per solver wave: mean %.2f, at the cap %.0f %%" % (name, 5 * m.mean(), np.mean(groups), 100 * np.mean(np.array(groups) >= 10)))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "ls":
+    ls_study()
