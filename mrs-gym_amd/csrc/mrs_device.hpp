@@ -113,9 +113,13 @@ MRS_DEV double rsqrt64(double x)
 // (scalar unit, off the VALU port the kernel is bound by).
 MRS_DEV double fma_c(double a, double b, double c)
 {
+#ifdef MRS_HOST_CHECK // tools/host_f32: these functions compiled for the CPU (diagnostics, tests/test_device_math_host.py) -- never the product
+    return __builtin_fma(a, b, c);
+#else
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
+#endif
 }
 MRS_DEV double ksin(double r)
 {

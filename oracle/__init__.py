@@ -107,6 +107,7 @@ def lib():
         _lib.orc_closest.argtypes = [PP, C.c_int, dp, dp, C.c_int, dp, dp, dp]
         _lib.orc_proximity.argtypes = [PP, C.c_int, dp, dp, dp]
         _lib.orc_contact_rows.argtypes = [PP, dp, dp, dp, dp, C.c_int]
+        _lib.orc_contact_solve.argtypes = [PP, dp, dp, dp, dp]
         _lib.orc_spawn_from.argtypes = [C.c_int, C.c_int, fp, C.c_double, fp]
         _lib.orc_spawn_from.restype = C.c_int
     return _lib
@@ -278,6 +279,13 @@ def contact_rows(params, pos, quat, v, w, n_sweeps):
     """The ground-contact rows of one body swept n_sweeps times without closed forms or early exits: returns (v, w) after."""
     v, w = f64(v).copy(), f64(w).copy()
     lib().orc_contact_rows(C.byref(params), _d(f64(pos)), _d(f64(quat)), _d(v), _d(w), int(n_sweeps))
+    return v, w
+
+
+def contact_solve(params, pos, quat, v, w):
+    """The model's ground-contact solve of one body (closed forms as params.rest_shortcut says, the model's stopping rules): (v, w) after."""
+    v, w = f64(v).copy(), f64(w).copy()
+    lib().orc_contact_solve(C.byref(params), _d(f64(pos)), _d(f64(quat)), _d(v), _d(w))
     return v, w
 
 

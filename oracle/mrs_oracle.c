@@ -591,6 +591,14 @@ void orc_contact_rows(const OrcParams *p, const double pos[3], const double quat
     quat_to_matrix_bullet(quat, R);
     contact_solve_ex(p, pos, R, v, w, n_sweeps, 0, 0);
 }
+/* test hook: the model's contact solve of one body on its own (closed forms by p->rest_shortcut, the model's stopping rules):
+ * what tests/test_device_math_host.py holds the kernel's contact function against */
+void orc_contact_solve(const OrcParams *p, const double pos[3], const double quat[4], double v[3], double w[3])
+{
+    double R[9];
+    quat_to_matrix_bullet(quat, R);
+    contact_solve_ex(p, pos, R, v, w, p->solver_iters, 1, p->rest_shortcut);
+}
 static void contact_solve_ex(const OrcParams *p, const double pos[3], const double R[9], double v[3], double w[3], int n_sweeps, int early_exit,
                              int closed_forms)
 {

@@ -138,6 +138,7 @@ void orc_integrate(const OrcParams *p, double pos[3], double quat[4], double vel
 /* test hook: the ground-contact rows of ONE body swept n_sweeps times, no closed forms, no early exits (v, w in/out: the
  * unconstrained velocities -> the constrained ones) */
 void orc_contact_rows(const OrcParams *p, const double pos[3], const double quat[4], double v[3], double w[3], int n_sweeps);
+void orc_contact_solve(const OrcParams *p, const double pos[3], const double quat[4], double v[3], double w[3]);
 
 /* ---- geometry sensors (mrs_sensors.c; Object.py:100-174 against the analytic scene; PARITY UNPINNED, see there) ---- */
 /* Object.raycast (Object.py:150-174) for agent `self` of ONE env: hit_obj -1 none / 0..N-1 quadcopter / N ground */

@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")"
 python3 gen_variant.py
 mkdir -p ../../build
-/opt/rocm/lib/llvm/bin/clang++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -Ishim contact_host.cpp -o ../../build/libcontact_host.so
+/opt/rocm/lib/llvm/bin/clang++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -DMRS_HOST_CHECK -Ishim contact_host.cpp -o ../../build/libcontact_host.so
 echo built build/libcontact_host.so

@@ -43,3 +43,16 @@ extern "C" void host_contact(const MrsParams *P, double pz, const double *q, con
     contact_solve_f32(*P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), a, b);
     dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dw[0] = b.x; dw[1] = b.y; dw[2] = b.z;
 }
+
+// One body through the step kernel's rigid-body pipeline (mrs_kernels.hip k_step: integrate_velocity -> contact_at_rest |
+// contact_stage -> integrate_pose), the device functions themselves: tests/test_device_math_host.py holds it against the oracle.
+extern "C" void host_body_step(const MrsParams *P, double *p, double *q, double *v, double *w, const double *fb, const double *tb)
+{
+    Recips K{};
+    K.inv_mass = 1.0 / P->mass; K.inv_i0 = 1.0 / P->inertia[0]; K.inv_i1 = 1.0 / P->inertia[1]; K.inv_i2 = 1.0 / P->inertia[2]; K.inv_dt = 1.0 / P->dt;
+    const double park_z = P->ground_z + std::sqrt(P->coll_radius * P->coll_radius + P->coll_half_len * P->coll_half_len) + P->contact_threshold;
+    const M3 Rb = quat_to_matrix_bullet(q[0], q[1], q[2], q[3]);
+    integrate_velocity(*P, K, Rb, v, w, v3(fb[0], fb[1], fb[2]), v3(tb[0], tb[1], tb[2]));
+    if (needs_contact(P->enable_contact, park_z, p[2]) && !(P->rest_shortcut && contact_at_rest(*P, K, p[2], q, v, w))) contact_stage(*P, K, p, q, v, w);
+    integrate_pose(*P, p, q, v, w);
+}
