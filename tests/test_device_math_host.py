@@ -128,3 +128,59 @@ def test_contact_statements_in_float64_are_the_oracles_algorithm(host):
         worst64 = max(worst64, float(np.abs(v + dv - ref[0]).max()), float(np.abs(w + dw - ref[1]).max()))
         n += 1
     assert n > 0 and worst64 < 1e-10, worst64
+
+
+MODE_CODE = {"accel": 3, "vel": 4, "pos": 5, "ori": 6}        # MRS_ACT_* (include/mrs_hip.h)
+
+
+@pytest.mark.parametrize("rounded", [0, 1])
+@pytest.mark.parametrize("mode", ["pos", "vel", "accel", "ori"])
+def test_F1_reference_controller_through_the_device_functions(host, golden_dir, mode, rounded):
+    """The reference's own QuadControl outputs (fixture F1: 256 quadcopters x 5 consecutive calls, a quarter at large attitude)
+    against the kernel's controller functions called in k_step's order (tools/host_f32/contact_host.cpp host_controller), both
+    controller forms (MrsParams.round_euler_readback).  Tolerance as on the GPU (tests/test_gpu_fixtures.py): 0.05 rpm -- the
+    Euler angles reach the controller through quaternion -> float32 -> matrix -> atan2, 1e-7 rad away from the fixture's, times
+    the attitude gain."""
+    H, mp, P = host
+    import copy
+    mp2 = copy.copy(mp)
+    mp2.round_euler_readback = rounded
+    fp = C.POINTER(C.c_float)
+    H.host_controller.argtypes = [C.c_void_p, C.c_void_p, C.c_int, fp, fp, fp, fp, fp, C.POINTER(C.c_double)]
+    d = np.load(os.path.join(golden_dir, "F1_quadcontrol.npz"))
+    m = [str(x) for x in d["modes"]].index(mode)
+    n, calls = d["rpm"].shape[1], d["rpm"].shape[2]
+    nb = H.host_pid_bytes()
+    worst = 0.0
+    f = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(fp)
+    for i in range(n):
+        mem = C.create_string_buffer(nb)
+        H.host_pid_init(mem)
+        for c in range(calls):
+            tgt = d["target"][i, c] * np.float32(0.3) if mode == "ori" else d["target"][i, c]
+            rpm = np.zeros(4)
+            H.host_controller(C.byref(mp2), mem, MODE_CODE[mode], f(d["pos"][i, c]), f(d["ori"][i, c]), f(d["vel"][i, c]), f(d["angvel"][i, c]),
+                              f(tgt), _d(rpm))
+            worst = max(worst, float(np.abs(rpm - d["rpm"][m, i, c]).max()))
+    assert worst < 0.05, worst
+
+
+def test_F2_reference_nnls_through_the_device_function(host, golden_dir):
+    """nnlsRPM (fixture F2, 43 % of the rows on the NNLS branch) against the kernel's closed-form set_control: rpm^2 within 2e-6
+    of the wrench scale of the reference's (the float32 rounding of the control input), as on the GPU."""
+    H, mp, P = host
+    fp = C.POINTER(C.c_float)
+    H.host_set_control.argtypes = [C.c_void_p, fp, C.POINTER(C.c_double)]
+    d = np.load(os.path.join(golden_dir, "F2_nnls.npz"))
+    k = np.array([P.mass, P.ixx_file, P.iyy_file, P.izz_file])
+    ctrl = (d["wrench"] / k).astype(np.float32)
+    bc = np.array([1 / P.kf, 1 / (P.kf * P.arm), 1 / (P.kf * P.arm), 1 / P.km])
+    w32 = (ctrl * k.astype(np.float32)).astype(np.float64)
+    scale = np.abs(w32 * bc).max(1) + 1.0
+    got = np.zeros((len(ctrl), 4))
+    for i, c in enumerate(ctrl):
+        H.host_set_control(C.byref(mp), np.ascontiguousarray(c).ctypes.data_as(fp), _d(got[i]))
+    assert d["nnls_branch"].mean() > 0.4
+    assert (np.abs(got ** 2 - d["rpm"] ** 2) / scale[:, None]).max() < 2e-6
+    orc = np.stack([oracle.set_control(c) for c in ctrl])
+    assert (np.abs(got ** 2 - orc ** 2) / scale[:, None]).max() < 1e-9            # closed-form split against Lawson-Hanson on the same input
