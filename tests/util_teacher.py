@@ -121,7 +121,10 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
         e = np.where(np.isfinite(e), e, np.inf)
         if dump is not None:   # diagnostic: the worst contact-phase cases with everything needed to replay them on the host
             thr = dump.get("thr", 5e-5)
-            for (ee, ii) in zip(*np.nonzero((e > thr) & (ph > 0))):
+            pick = (e > thr) & (ph > 0)
+            if unconstrained and "vmax" in dump:       # only bodies whose contact solve was handed less than this (m/s)
+                pick &= vu < dump["vmax"]
+            for (ee, ii) in zip(*np.nonzero(pick)):
                 if len(dump.setdefault("cases", [])) < dump.get("max", 400):
                     dump["cases"].append(dict(t=t, env=int(ee), agent=int(ii), phase=int(ph[ee, ii]), err=float(e[ee, ii]),
                                               pre=np.concatenate([pre[k][ee, ii] for k in ("pos", "quat", "vel", "angvel")]),

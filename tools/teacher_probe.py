@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--envs", type=int, default=32)
     ap.add_argument("--configs", default="C2,C3,C4,C5")
     ap.add_argument("--solver-iters", type=int, default=0)
+    ap.add_argument("--adj-every", type=int, default=1, help="compare adjacency / observation with the oracle every k-th step (large --envs)")
     ap.add_argument("--dump", default="", help="write the worst contact-phase cases (pre-state, both post-states, wrench) to this .npz")
     a = ap.parse_args()
     print("teacher-forced per-step error |GPU - oracle| (max over the 13 state words, relative above magnitude 1),")
@@ -34,7 +35,9 @@ def main():
             params.solver_iters = a.solver_iters
         t0 = time.time()
         dump = {"thr": float(os.environ.get("DUMP_THR", "5e-5")), "max": 400} if a.dump else None
-        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump, unconstrained=True,
+        if dump and os.environ.get("DUMP_VMAX"):
+            dump["vmax"] = float(os.environ["DUMP_VMAX"])
+        r = ut.run(torch, mrsgym_amd, cfg, E=a.envs, steps=a.steps, params=params, dump=dump, unconstrained=True, check_adj_every=a.adj_every,
                    progress=lambda t: print("   ... %s step %d (%.0f s)" % (cfg, t, time.time() - t0), flush=True))
         print("%s  N=%d  %s  solver_iters=%d  grounded at the end %.0f %%  adjacency/observation mismatches %d  visited %s"
               % (cfg, r["N"], ut.CONFIGS[cfg]["atype"], int((params or mrsgym_amd.default_params()).solver_iters),
