@@ -361,11 +361,21 @@ MRS_DEV float div_ctrl_dt(float x, float dt32, const Recips &K)
     // and a zero or subnormal first quotient loses the sign of zero / is rounded twice -- those go through the division
     // proper.  One v_cmp_class_f32 (+-normal); measured against round 3's unguarded form: 22.95 / 23.01 against 22.51 / 22.62 us
     // per step with two compares and an or, inside the noise with the class test (tools/abl_run.sh).
+    // Round 5: branch-free.  The refined quotient is formed unconditionally and a select keeps q0 where q0 is not +-normal: q0 IS
+    // the division's result for x = +-inf, NaN and +-0 and for an overflowing product; a subnormal q0 (|x| < 1.2e-40) may differ from
+    // the correctly rounded quotient by one subnormal ulp (1.4e-45).  The divergent branch around the division sequence cost
+    // 0.3 - 0.9 us per step in a same-box A/B (gpurun_out/r4y/c3b.txt), three of them per agent-step.
 #ifndef MRS_DIV_GUARD
-#define MRS_DIV_GUARD 1 // A/B switch: 0 = round 3's unguarded form
+#define MRS_DIV_GUARD 2 // A/B switch: 0 = round 3's unguarded form, 1 = round 4's branch to the division proper, 2 = select
 #endif
-    if (MRS_DIV_GUARD && !__builtin_amdgcn_class(q0, 0x008 | 0x100)) return f32div(x, dt32);
-    return __builtin_fmaf(__builtin_fmaf(-dt32, q0, x), K.inv_ctrl_dt32, q0);
+#ifdef MRS_HOST_CHECK
+    const bool normal = __builtin_isnormal(q0);
+#else
+    const bool normal = __builtin_amdgcn_class(q0, 0x008 | 0x100);
+#endif
+    if (MRS_DIV_GUARD == 1 && !normal) return f32div(x, dt32);
+    const float q = __builtin_fmaf(__builtin_fmaf(-dt32, q0, x), K.inv_ctrl_dt32, q0);
+    return (MRS_DIV_GUARD == 2 && !normal) ? q0 : q;
 }
 
 // Controller memory of one quadcopter, in registers for the duration of a step.

@@ -104,10 +104,12 @@ __device__ __forceinline__ WgBuffers wg_buffers(const StepArgs &A, size_t wg_bas
 {
     WgBuffers w;
     w.pos = A.b.pos + wg_base; w.quat = A.b.quat + wg_base; w.vel = VELP(A.b.vel) + wg_base; w.angvel = VELP(A.b.angvel) + wg_base;
-    w.pid = A.b.pid ? reinterpret_cast<float4 *>(A.b.pid) + wg_base : nullptr;
-    w.rpm = A.b.rpm ? A.b.rpm + wg_base : nullptr;
-    w.obs = A.b.obs ? A.b.obs + wg_base * (size_t)A.D : nullptr;
-    w.adj = A.b.adj ? A.b.adj + wg_base * (size_t)A.W : nullptr;
+    // (no null tests: a base formed from a null pointer is never dereferenced -- every use sits behind a test of the MrsBuffers
+    // member itself -- and without the tests the scalar loads of the four pointers go out together instead of one round trip each)
+    w.pid = reinterpret_cast<float4 *>(A.b.pid) + wg_base;
+    w.rpm = A.b.rpm + wg_base;
+    w.obs = A.b.obs + wg_base * (size_t)A.D;
+    w.adj = A.b.adj + wg_base * (size_t)A.W;
     return w;
 }
 __device__ __forceinline__ void load_state(const WgBuffers &b, unsigned t, size_t T, double p[3], double q[4], double v[3], double w[3])
@@ -618,11 +620,11 @@ __device__ __forceinline__ void adjacency_blocks(const StepArgs &A, float thr_s,
 // the LDS position tile.  Contains a workgroup barrier: every thread of the workgroup must call it.
 // Also (A.pair_flag): notes per env whether any pair of it is within quad-quad contact range of these positions -- the
 // squared distances are formed here anyway -- for the step that starts from them.  row may be null (flag only).
-template <int BLOCK>
+template <int BLOCK, bool N64 = false>
 __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, bool comm_inf, float4 *lds_tile, int tid, int el, int i, bool live,
                                                 uint64_t *row, float4 mine, int e)
 {
-    const bool n64 = A.N == 64;
+    const bool n64 = N64 || A.N == 64; // N64: the N = 64 instantiation of k_step (the other branches fold away)
     // A NaN (or infinite) position -- a diverged or mis-set body -- is adjacent to nobody: torch's `dist <= R` is False for a
     // NaN distance (MRS.py:121).  The sign-bit verdicts below read the sign of d^2 - T', and a NaN carries a sign of its own
     // through the arithmetic (x86 hands out negative ones, and the negate modifiers of the packed subtractions flip them), so no
@@ -632,7 +634,7 @@ __device__ __forceinline__ void adjacency_phase(const StepArgs &A, float thr_s, 
         const float far = 1e18f * (float)(1 + i);
         mine.x = fabsf(mine.x) <= 1e17f ? mine.x : far; mine.y = fabsf(mine.y) <= 1e17f ? mine.y : far; mine.z = fabsf(mine.z) <= 1e17f ? mine.z : far;
     }
-    if constexpr (BLOCK == 256) {
+    if constexpr (BLOCK == 256 && !N64) {
         if (A.N > 64 && (A.N & 63) == 0) { // 128, 192, 256
             adjacency_blocks<BLOCK>(A, thr_s, comm_inf, lds_tile, tid, el, i, live, row, mine, e);
             return;
@@ -881,17 +883,28 @@ __device__ __forceinline__ void pair_contact_term(const StepArgs &A, float rx, f
 // three-launch form pays it three times (measured: tools/micro/launch_floor.hip).
 // FUSED = false: velocities only; grounded bodies are queued for k_contact, observation/adjacency follow in
 // k_observe_adj (N_AGENTS > 256, or MRS_STEP_SPLIT=1).
-template <int ACT, int BLOCK, bool FUSED>
-__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : (FUSED ? 4 : 1))) void k_step(const StepArgs A)
+// Kernel-argument preload (round 5): the first 14 dwords of the argument segment -- the sizes and the pointers of the first loads,
+// handed over as scalar parameters of their own AHEAD of the struct that holds them too -- arrive in SGPRs with the wave
+// (-mllvm -amdgpu-kernarg-preload-count=14, gfx950 user SGPRs: 2 for the segment pointer + 14), so that the action and position
+// loads are issued without a scalar-cache round trip first: every wave of the launch starts on a cold scalar cache, and the
+// timeline stamps put "arguments arrived" 0.75 us after the wave's start.  The struct's own copies serve everything later.
+#define MRS_STEP_PRE int pE, int pN, int pT, int pEPB, const float *pact, const double *ppos, const double *pquat, const vel_t *pvel, const vel_t *pangvel
+#define MRS_STEP_PRE_ARGS(S) (S).E, (S).N, (S).T, (S).epb, (S).actions, (S).b.pos, (S).b.quat, VELP((S).b.vel), VELP((S).b.angvel)
+// N64 (round 5): the instantiation for N_AGENTS = 64 (one env per wave, BLOCK / 64 envs per workgroup): N, the envs per workgroup and
+// the row width are compile-time constants, the index division is a shift and the branches of the other layouts (generic N, envs
+// of several waves, the ring) are not in the kernel's text at all -- 14 000 lines of assembly with them, the path of an N = 64
+// wave threaded through it.
+template <int ACT, int BLOCK, bool FUSED, bool N64 = false>
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : MRS_MIN_WAVES) : (FUSED ? 4 : 1))) void k_step(MRS_STEP_PRE, const StepArgs A)
 {
-    const int AN = A.N, AEPB = A.epb, AW = A.W;
+    const int AN = N64 ? 64 : pN, AEPB = N64 ? BLOCK / 64 : pEPB, AW = N64 ? 1 : A.W;
     extern __shared__ float4 lds_tile[]; // BLOCK positions (doubled for N = 64), then one int flag per env slot
     int *nanflag = reinterpret_cast<int *>(lds_tile + 2 * BLOCK); // [256] read once (the NaN vote below) and DEAD afterwards:
                                                                   // adjacency_blocks reuses it in the tail as its third exchange array
     int *ncontact = nanflag + 256; // bodies of this workgroup that need the contact solve
     // N = 64 layout: each env's 64 positions are stored TWICE back to back (128 slots per env) so that
     // "neighbour (lane + k) mod 64" is the un-wrapped slot lane + k: a constant LDS offset per unrolled k
-    const bool n64 = (AN == 64);
+    const bool n64 = N64 || (AN == 64);
 
     const int tid = threadIdx.x;
 #ifdef MRS_TIMELINE // diagnostic build (tools/probes/timeline_probe.py): lane 0 of every wave stamps clock64() at the phase
@@ -912,12 +925,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     const int el = tid / AN;
     const int i = tid - el * AN;
     const int e = blockIdx.x * AEPB + el;
-    const bool live = (el < AEPB) && (e < A.E);
-    const size_t T = (size_t)A.T;
+    const bool live = (el < AEPB) && (e < pE);
+    const size_t T = (size_t)pT;
     const size_t a = live ? (size_t)e * AN + i : 0;
     const unsigned la = live ? (unsigned)tid : 0u;                                        // a == wg_base + la
     const size_t wb_base = (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN;
-    const WgBuffers wb = wg_buffers(A, wb_base);
+    WgBuffers wb;
+    wb.pos = const_cast<double *>(ppos) + wb_base; wb.quat = const_cast<double *>(pquat) + wb_base; // the preloaded copies
+    wb.vel = const_cast<vel_t *>(pvel) + wb_base; wb.angvel = const_cast<vel_t *>(pangvel) + wb_base;
     constexpr int ADIM = (ACT == MRS_ACT_SET_SPEEDS || ACT == MRS_ACT_SET_CONTROL) ? 4 : 3;
 
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
@@ -932,7 +947,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         // action (NaN vote) and the position (LDS tile, pair loop) first, so that the quaternion and the velocities
         // are still in flight while the pair loop runs instead of being waited for up front.
         if (ACT != MRS_ACT_NONE) {
-            const float *ap = A.actions + (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN * ADIM;
+            const float *ap = pact + (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN * ADIM;
 #pragma unroll
             for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
         }
@@ -946,6 +961,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #if MRS_DEFER_LOADS
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    {   // the other buffers' workgroup bases come from the struct (scalar loads): formed behind the first loads, not ahead of them
+        const WgBuffers w2 = wg_buffers(A, wb_base);
+        wb.pid = w2.pid; wb.obs = w2.obs; wb.rpm = w2.rpm; wb.adj = w2.adj;
+    }
     double downwash_acc = 0;
     // N = 64 (one env per wave): the three-array tile of the packed pair loop (tile64_write); any other N, and the
     // MRS_EXACT_F32 build's all-pairs loop: one float4 per agent
@@ -1416,7 +1435,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/probes/sweeps_probe.py); the run's physics is void
                     float dg[2] = {0.f, 0.f};
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw, dg);
-                    if (wb.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
+                    if (A.b.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
 #else
                     contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw);
 #endif
@@ -1471,7 +1490,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             int t2 = tid;
             asm volatile("" : "+v"(t2));
             const int e2 = blockIdx.x * AEPB + (n64 ? (t2 >> 6) : el);
-            adjacency_phase<BLOCK>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
+            adjacency_phase<BLOCK, N64>(A, A.d2_thresh, A.comm_inf != 0 || !A.do_adj, lds_tile, tid, el, i, live,
                                          A.do_adj ? wb.adj + la * (unsigned)AW : nullptr,
                                          make_float4(fpx, fpy, fpz, 0.f), e2);
         }
@@ -1986,7 +2005,7 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
     }
     if (const char *sb = getenv("MRS_STEP_BLOCK")) {
         const int v = atoi(sb);
-        if ((v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) && v >= n_agents && n_agents <= 256) h->sblock = v;
+        if ((v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) && n_agents == 64) h->sblock = v; // (the other workgroup sizes exist as N = 64 instantiations only)
     }
     h->cached = nullptr;
     mrs_set_params(h, params);
@@ -2126,29 +2145,30 @@ static hipError_t launch_step(MrsHandle *h, const StepArgs &A, hipStream_t st, b
         B.epb = std::min(h->sblock / h->N, 256); // whole envs per workgroup (the NaN-flag array holds 256)
         const int g = (h->E + B.epb - 1) / B.epb;
         const size_t l = 2 * (size_t)h->sblock * sizeof(float4) + 258 * sizeof(int) + (size_t)h->sblock * sizeof(int) + 13 * (size_t)h->sblock * sizeof(double) + (size_t)(h->sblock / 64) * sizeof(int);
-        if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true>), dim3(g), dim3(128), l, st, B);
+        if (h->sblock == 128) hipLaunchKernelGGL((k_step<ACT, 128, true, true>), dim3(g), dim3(128), l, st, MRS_STEP_PRE_ARGS(B), B);
         else if (h->sblock == 512) { // 74 KB of LDS per workgroup: above the 64 KB default limit of a launch
             // The attribute belongs to the (function, device) pair and a process may hold handles on several devices: noted per
             // handle (a handle is bound to one device and is not thread-safe, include/mrs_hip.h) and per ACTION_TYPE instantiation.
             if (!h->big_lds[ACT]) {
-                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 512, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
                 if (ea != hipSuccess) return ea;
                 h->big_lds[ACT] = true;
             }
-            hipLaunchKernelGGL((k_step<ACT, 512, true>), dim3(g), dim3(512), l, st, B);
+            hipLaunchKernelGGL((k_step<ACT, 512, true, true>), dim3(g), dim3(512), l, st, MRS_STEP_PRE_ARGS(B), B);
         } else if (h->sblock == 1024) {
             if (!h->big_lds[ACT]) {
-                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<ACT, 1024, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
                 if (ea != hipSuccess) return ea;
                 h->big_lds[ACT] = true;
             }
-            hipLaunchKernelGGL((k_step<ACT, 1024, true>), dim3(g), dim3(1024), l, st, B);
+            hipLaunchKernelGGL((k_step<ACT, 1024, true, true>), dim3(g), dim3(1024), l, st, MRS_STEP_PRE_ARGS(B), B);
         }
-        else hipLaunchKernelGGL((k_step<ACT, 64, true>), dim3(g), dim3(64), l, st, B);
+        else hipLaunchKernelGGL((k_step<ACT, 64, true, true>), dim3(g), dim3(64), l, st, MRS_STEP_PRE_ARGS(B), B);
     } else
-    if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, A);
-    else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, A);
+    if (fused && h->N == 64) hipLaunchKernelGGL((k_step<ACT, 256, true, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, MRS_STEP_PRE_ARGS(A), A);
+    else if (fused) hipLaunchKernelGGL((k_step<ACT, 256, true>), dim3(grid), dim3(256), lds + 256 * sizeof(int) + 13 * 256 * sizeof(double) + 4 * sizeof(int), st, MRS_STEP_PRE_ARGS(A), A);
+    else if (h->block == 256) hipLaunchKernelGGL((k_step<ACT, 256, false>), dim3(grid), dim3(256), lds, st, MRS_STEP_PRE_ARGS(A), A);
+    else hipLaunchKernelGGL((k_step<ACT, 1024, false>), dim3(grid), dim3(1024), lds, st, MRS_STEP_PRE_ARGS(A), A);
     return hipGetLastError();
 }
 

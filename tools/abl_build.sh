@@ -2,7 +2,7 @@
 # Build ablation variants of the library: tools/abl_build.sh name1 "-DFLAG=1 ..." name2 "..." ...  -> build/abl/lib<name>.so
 set -e
 mkdir -p build/abl
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -fno-slp-vectorize"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -fno-slp-vectorize ${MRS_PRELOAD--mllvm -amdgpu-kernarg-preload-count=14}"
 pids=()
 while [ $# -gt 0 ]; do
   name=$1; defs=$2; shift 2

@@ -4,7 +4,7 @@
 import os, re, subprocess, sys, shutil, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = tempfile.mktemp(suffix=".so")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"] + sys.argv[1:] + [
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14"] + sys.argv[1:] + [
     "-Rpass-analysis=kernel-resource-usage", os.path.join(ROOT, "mrs-gym_amd/csrc/mrs_kernels.hip"), "-o", out]
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr
 if os.path.exists(out):

@@ -9,7 +9,7 @@ import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 flags = sys.argv[1:]
 out = "/tmp/isa_sections.s"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DMRS_MARKS",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-DMRS_MARKS",
                        "-S", "--cuda-device-only", os.path.join(ROOT, "mrs-gym_amd/csrc/mrs_kernels.hip"), "-o", out] + flags,
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()

@@ -1,6 +1,6 @@
 """Diagnostic: per-wave phase timestamps of the fused step kernel (profiles/r01_timeline.txt).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -DMRS_TIMELINE \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=14 -DMRS_TIMELINE \
           mrs-gym_amd/csrc/mrs_kernels.hip -o build/abl/libmrs_tl.so
     MRS_HIP_LIB=build/abl/libmrs_tl.so python tools/probes/timeline_probe.py        (on the GPU box)
 
