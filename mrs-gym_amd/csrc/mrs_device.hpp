@@ -679,155 +679,224 @@ struct F3 {
 // two float32 in an aligned register pair: the operand of the packed instructions (v_pk_fma_f32: two fused
 // multiply-adds for the issue cost of one, tools/micro/valu_rates2.hip)
 typedef float F2 __attribute__((ext_vector_type(2)));
-// Returns the velocity CHANGES (dv, dw) in float32; the caller adds them to the float64 state (the fused kernel re-reads
-// that from its LDS stash afterwards, so no float64 velocity stays live across the sweeps).
-MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, const double q[4], const V3 &v, const V3 &w, F3 &dv_out, F3 &dw_out,
-                               float *diag = nullptr)
+// The rows' scalar type is a template parameter: float in every kernel; double only in the CPU suite, which runs the SAME
+// statements in float64 against the oracle (tests/test_device_math_host.py: 1e-12 -- what is left between the kernel and the
+// oracle is float32, not the algorithm).  (Rounds 3-4 derived the float64 text from this function by regular expressions.)
+template <class S> struct ContactT;
+template <> struct ContactT<float> {
+    typedef float S2 __attribute__((ext_vector_type(2)));
+    static MRS_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static MRS_DEV float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+    static MRS_DEV float med3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+    static MRS_DEV float max(float a, float b) { return fmaxf(a, b); }
+    static MRS_DEV float abs(float a) { return fabsf(a); }
+};
+template <> struct ContactT<double> {
+    typedef double S2 __attribute__((ext_vector_type(2)));
+    static MRS_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static MRS_DEV double rcp(double a) { return 1.0 / a; }
+    static MRS_DEV double med3(double a, double lo, double hi) { return a < lo ? lo : (a > hi ? hi : a); }
+    static MRS_DEV double max(double a, double b) { return a > b ? a : b; }
+    static MRS_DEV double abs(double a) { return a < 0 ? -a : a; }
+};
+// ---- Round 5: the equal-share start is applied in its SYMMETRIC form.  A body pressed into the ground at the velocity clamp (100 m/s
+// in every component under the reference's downwash singularity) needs impulses of ~0.7 N s per rim point whose angular responses --
+// 4000 rad/s per N s each -- cancel between the points; added up as four float32 products they leave 1e-7 of themselves, and the
+// sweeps then spend their float32 resolution on cancelling 100 m/s.  So the start's effect on the body is formed once, as
+// dv_z = n l0 / m in float64 and dw = l0 Iw ((sum of the active levers) x z) with the sum taken as n cz + (a0 - a3) ca + (a2 - a1) cb
+// (the half-diagonals of a body lying on all four points cancel identically), it goes into the body's float64 velocities at once,
+// and the sweeps accumulate only their corrections to the velocities it leaves: a body pressed flat hands them a residual of zero.
+// Worst teacher-forced error of the fastest bodies 3.2e-4 -> 1.8e-4, of everything below 50 m/s <= 6e-5 (profiles/r05_teacher_forced.txt).
+// (Built, measured and NOT kept in round 5: a float64 re-linearisation after the first pair of sweeps -- impulses applied exactly
+// through float64 geometry, right-hand sides formed anew, the remaining sweeps on small corrections -- brings every class below 1e-4
+// (6e-5 ... 9e-5), but its register pressure costs the step kernel scratch memory, and a k_step that touches scratch at all runs
+// 2 - 3 us slower (the scratch ring throttles the resident waves); and four lanes per body in impulse space, 25 % fewer instructions on
+// the solving wave (-0.6 us per step) but without the velocity feedback that makes the one-lane form forgiving: 3e-4 ... 9e-4.)
+// One lane per body, the rows in velocity space.  `body` is the body's float64 velocities: load(v, w) reads them, add(dv, dw) applies
+// a change -- the start's at once, the sweeps' float32 corrections at the end (the fused kernel keeps them in its LDS stash: no
+// float64 word is live across the sweeps).
+template <class S, class Body>
+MRS_DEV void contact_solve_rows(const MrsParams &P, const Recips &K, double pz, const double q[4], Body &&body, float *diag = nullptr)
 {
     // Every product-sum below is written out with explicit fused multiply-adds under "contract(off)": the function is inlined
     // into several kernels (one-launch step, k_contact) and must round the same way in all of them.
 #pragma clang fp contract(off)
-    dv_out = F3{0.f, 0.f, 0.f}; dw_out = F3{0.f, 0.f, 0.f};
-    // Everything from here on is float32, the geometry included (round 3; round 2 formed the rotation matrix, the rim points'
+    typedef ContactT<S> M;
+    typedef typename M::S2 S2;
+    struct S3 { S x, y, z; };
+    // Everything from here on is S (float32 in the kernels), the geometry included (round 3; round 2 formed the rotation matrix, the rim points'
     // heights, the gaps and the right-hand sides in float64: ~150 float64 instructions and conversions at the head of the
     // workgroup's one serial chain).  What float32 costs: the levers (|r| <= 0.061 m) carry the quaternion's rounding, < 1e-8 m;
     // the gap is the float32 of (pz - ground_z), rounded once from the float64 difference, plus the lever's z, < 2e-9 m off;
     // times 1 / dt that is < 2e-7 m/s on a right-hand side -- three orders inside the stated 1e-4 per step.
-    const float c = (float)(P.coll_radius * 0.70710678118654752440), hl = (float)P.coll_half_len;
-    const float i0 = (float)K.inv_i0, i1 = (float)K.inv_i1, i2 = (float)K.inv_i2;
-    const float im = (float)K.inv_mass;
-    const auto fm = [](float a, float b, float c) { return __builtin_fmaf(a, b, c); };
-    // btMatrix3x3::setRotation of the float32 quaternion, s = 2 / |q|^2
-    const float qx = (float)q[0], qy = (float)q[1], qz = (float)q[2], qw = (float)q[3];
-    const float s2 = 2.0f * __builtin_amdgcn_rcpf(fm(qx, qx, fm(qy, qy, fm(qz, qz, qw * qw))));
-    const float xs = qx * s2, ys = qy * s2, zs = qz * s2;
-    const float r00 = 1.0f - fm(qy, ys, qz * zs), r01 = fm(qx, ys, -(qw * zs)), r02 = fm(qx, zs, qw * ys);
-    const float r10 = fm(qx, ys, qw * zs), r11 = 1.0f - fm(qx, xs, qz * zs), r12 = fm(qy, zs, -(qw * xs));
-    const float r20 = fm(qx, zs, -(qw * ys)), r21 = fm(qy, zs, qw * xs), r22 = 1.0f - fm(qx, xs, qy * ys);
-    // world inverse inertia R diag(i0, i1, i2) R^T
-    const float a00 = r00 * i0, a01 = r01 * i1, a02 = r02 * i2, a10 = r10 * i0, a11 = r11 * i1, a12 = r12 * i2;
-    const float Ixx = fm(a00, r00, fm(a01, r01, a02 * r02)), Ixy = fm(a00, r10, fm(a01, r11, a02 * r12)), Ixz = fm(a00, r20, fm(a01, r21, a02 * r22));
-    const float Iyy = fm(a10, r10, fm(a11, r11, a12 * r12)), Iyz = fm(a10, r20, fm(a11, r21, a12 * r22));
-    const float Izz = fm(r20 * i0, r20, fm(r21 * i1, r21, (r22 * i2) * r22));
-    // only the rim of the cap facing the ground carries contacts (oracle: lower_cap): fold its sign into the cap's offset
-    const float shl = (r22 >= 0.f) ? -hl : hl;
-    const F3 cz = {shl * r02, shl * r12, shl * r22};
-    // the four rim points (+-c, +-c) in the cap's plane: centre offset +- (cx + cy) and +- (cx - cy)
-    const F3 ca = {c * (r00 + r01), c * (r10 + r11), c * (r20 + r21)}, cb = {c * (r00 - r01), c * (r10 - r11), c * (r20 - r21)};
-    const float d0 = (float)(pz - P.ground_z);
-    const float thr = (float)P.contact_threshold, rdt = (float)K.inv_dt, erdt = (float)(P.erp * K.inv_dt);
-    const float v0z = (float)v.z;
-    bool any = false;
-    float ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4];
+    const S im = (S)K.inv_mass;
+    const auto fm = [](S a, S b, S c) { return M::fma(a, b, c); };
+    bool any = false, cap_down = false;
+    S ln[4], lx[4], ly[4], Kn[4], Kx[4], Ky[4], rhs[4], gapv[4];
     // per point, constant over the sweeps: lever r and the angular responses Iw (r x d) of the three rows.
     // Branch-free: every lane prepares all four rim points; a point that is not within the contact threshold gets
     // zero effective masses, which turns its three rows into exact no-ops (impulses stay 0) -- no per-point
     // exec-mask round trips in the sweeps and nothing to zero-initialise.
-    F3 r[4];
-    F2 anxy[4], axxy[4], ayxy[4]; // x, y of the angular responses as pairs: dw.xy += a.xy * dl is one packed fma
-    float anz[4], axz[4], ayz[4];
-    const float w0x = (float)w.x, w0y = (float)w.y, w0z = (float)w.z;
+    S3 r[4];
+    S2 anxy[4], axxy[4], ayxy[4]; // x, y of the angular responses as pairs: dw.xy += a.xy * dl is one packed fma
+    S anz[4], axz[4], ayz[4];
+    S rsx = (S)0, rsy = (S)0, nact = (S)0; // the start's lever sum (x, y) and the number of active points
+    S Ixx, Ixy, Ixz, Iyy, Iyz;
+    // the geometry, the responses and the effective masses from the quaternion
+    const auto prepare = [&](S qx, S qy, S qz, S qw) {
+        const S c = (S)(P.coll_radius * 0.70710678118654752440), hl = (S)P.coll_half_len;
+        const S i0 = (S)K.inv_i0, i1 = (S)K.inv_i1, i2 = (S)K.inv_i2;
+        // btMatrix3x3::setRotation of the quaternion, s = 2 / |q|^2
+        const S s2 = (S)2 * M::rcp(fm(qx, qx, fm(qy, qy, fm(qz, qz, qw * qw))));
+        const S xs = qx * s2, ys = qy * s2, zs = qz * s2;
+        const S r00 = (S)1 - fm(qy, ys, qz * zs), r01 = fm(qx, ys, -(qw * zs)), r02 = fm(qx, zs, qw * ys);
+        const S r10 = fm(qx, ys, qw * zs), r11 = (S)1 - fm(qx, xs, qz * zs), r12 = fm(qy, zs, -(qw * xs));
+        const S r20 = fm(qx, zs, -(qw * ys)), r21 = fm(qy, zs, qw * xs), r22 = (S)1 - fm(qx, xs, qy * ys);
+        // world inverse inertia R diag(i0, i1, i2) R^T
+        const S a00 = r00 * i0, a01 = r01 * i1, a02 = r02 * i2, a10 = r10 * i0, a11 = r11 * i1, a12 = r12 * i2;
+        Ixx = fm(a00, r00, fm(a01, r01, a02 * r02)); Ixy = fm(a00, r10, fm(a01, r11, a02 * r12)); Ixz = fm(a00, r20, fm(a01, r21, a02 * r22));
+        Iyy = fm(a10, r10, fm(a11, r11, a12 * r12)); Iyz = fm(a10, r20, fm(a11, r21, a12 * r22));
+        const S Izz = fm(r20 * i0, r20, fm(r21 * i1, r21, (r22 * i2) * r22));
+        // only the rim of the cap facing the ground carries contacts (oracle: lower_cap): fold its sign into the cap's offset
+        cap_down = r22 >= (S)0;
+        const S shl = cap_down ? -hl : hl;
+        const S3 cz = {shl * r02, shl * r12, shl * r22};
+        // the four rim points (+-c, +-c) in the cap's plane: centre offset +- (cx + cy) and +- (cx - cy)
+        const S3 ca = {c * (r00 + r01), c * (r10 + r11), c * (r20 + r21)}, cb = {c * (r00 - r01), c * (r10 - r11), c * (r20 - r21)};
+        const S d0 = (S)(pz - P.ground_z);
+        const S thr = (S)P.contact_threshold, rdt = (S)K.inv_dt, erdt = (S)(P.erp * K.inv_dt);
+        any = false; nact = (S)0;
+        S aact[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // k & 1: -cx, k & 2: -cy  =>  k = 0: +ca, 1: -cb, 2: +cb, 3: -ca
+            const S3 &o = (k == 0 || k == 3) ? ca : cb;
+            const bool plus = (k == 0 || k == 2);
+            const S rx = plus ? cz.x + o.x : cz.x - o.x, ry = plus ? cz.y + o.y : cz.y - o.y, rz = plus ? cz.z + o.z : cz.z - o.z;
+            r[k] = S3{rx, ry, rz};
+            const S dist = d0 + rz;
+            const bool act = dist <= thr;
+            any |= act;
+            // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
+            const S3 an = {fm(Ixx, ry, -(Ixy * rx)), fm(Ixy, ry, -(Iyy * rx)), fm(Ixz, ry, -(Iyz * rx))};
+            const S3 ax = {fm(Ixy, rz, -(Ixz * ry)), fm(Iyy, rz, -(Iyz * ry)), fm(Iyz, rz, -(Izz * ry))};
+            const S3 ay = {fm(Ixz, rx, -(Ixx * rz)), fm(Iyz, rx, -(Ixy * rz)), fm(Izz, rx, -(Ixz * rz))};
+            anxy[k] = S2{an.x, an.y}; anz[k] = an.z; axxy[k] = S2{ax.x, ax.y}; axz[k] = ax.z; ayxy[k] = S2{ay.x, ay.y}; ayz[k] = ay.z;
+            // effective masses 1 / (1/m + (r x d) . Iw (r x d))
+            const S kn = M::rcp(fm(ry, an.x, fm(-rx, an.y, im)));
+            const S kx = M::rcp(fm(rz, ax.y, fm(-ry, ax.z, im)));
+            const S ky = M::rcp(fm(rx, ay.z, fm(-rz, ay.x, im)));
+            Kn[k] = act ? kn : (S)0; Kx[k] = act ? kx : (S)0; Ky[k] = act ? ky : (S)0;
+            // Bullet-style target normal velocity: open gap -> let the point close it this step; penetration -> erp push-out
+            gapv[k] = -dist * (dist > (S)0 ? rdt : erdt);
+            aact[k] = act ? (S)1 : (S)0;
+            nact += aact[k];
+            __builtin_amdgcn_sched_barrier(0); // one point after the other: interleaved, the four points' temporaries cost three spilled registers
+        }
+        // the active levers' sum in its symmetric form, n cz + (a0 - a3) ca + (a2 - a1) cb (x, y: rs x z = (rs.y, -rs.x, 0))
+        const S sa = aact[0] - aact[3], sb = aact[2] - aact[1];
+        rsx = fm(nact, cz.x, fm(sa, ca.x, sb * cb.x)); rsy = fm(nact, cz.y, fm(sa, ca.y, sb * cb.y));
+    };
+    prepare((S)q[0], (S)q[1], (S)q[2], (S)q[3]);
+    if (!any) return;
+    const S mu = (S)P.friction;
+    // Start of the sweeps (the oracle's contact_solve does the same): every active point carries the equal share of the
+    // impulse that stops the mean closing velocity, l0 = m max(sum rhs, 0) / n^2 -- exact for a body lying flat, which
+    // then needs no iteration; the sweeps correct it for everything else.  From a cold start 90 % of the grounded
+    // bodies needed 8-10 sweeps, with this start 86 % are done after the first pair (tools/probes/sweeps_probe.py).
+    V3 v, w;
+    body.load(v, w);
+    S v0x = (S)v.x, v0y = (S)v.y, v0z = (S)v.z, w0x = (S)w.x, w0y = (S)w.y, w0z = (S)w.z; // the unconstrained velocities as they come
+    S rsum = (S)0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        ln[k] = lx[k] = ly[k] = 0.f;
-        // k & 1: -cx, k & 2: -cy  =>  k = 0: +ca, 1: -cb, 2: +cb, 3: -ca
-        const F3 &o = (k == 0 || k == 3) ? ca : cb;
-        const bool plus = (k == 0 || k == 2);
-        const float rx = plus ? cz.x + o.x : cz.x - o.x, ry = plus ? cz.y + o.y : cz.y - o.y, rz = plus ? cz.z + o.z : cz.z - o.z;
-        r[k] = F3{rx, ry, rz};
-        const float dist = d0 + rz;
-        const bool act = dist <= thr;
-        any |= act;
-        // Iw u for u = r x z = (ry,-rx,0), r x x = (0,rz,-ry), r x y = (-rz,0,rx)
-        const F3 an = {fm(Ixx, ry, -(Ixy * rx)), fm(Ixy, ry, -(Iyy * rx)), fm(Ixz, ry, -(Iyz * rx))};
-        const F3 ax = {fm(Ixy, rz, -(Ixz * ry)), fm(Iyy, rz, -(Iyz * ry)), fm(Iyz, rz, -(Izz * ry))};
-        const F3 ay = {fm(Ixz, rx, -(Ixx * rz)), fm(Iyz, rx, -(Ixy * rz)), fm(Izz, rx, -(Ixz * rz))};
-        anxy[k] = F2{an.x, an.y}; anz[k] = an.z; axxy[k] = F2{ax.x, ax.y}; axz[k] = ax.z; ayxy[k] = F2{ay.x, ay.y}; ayz[k] = ay.z;
-        // effective masses 1 / (1/m + (r x d) . Iw (r x d))
-        const float kn = __builtin_amdgcn_rcpf(fm(ry, an.x, fm(-rx, an.y, im)));
-        const float kx = __builtin_amdgcn_rcpf(fm(rz, ax.y, fm(-ry, ax.z, im)));
-        const float ky = __builtin_amdgcn_rcpf(fm(rx, ay.z, fm(-rz, ay.x, im)));
-        Kn[k] = act ? kn : 0.f; Kx[k] = act ? kx : 0.f; Ky[k] = act ? ky : 0.f;
-        const float vrel0 = fm(w0x, ry, fm(-w0y, rx, v0z));
-        // Bullet-style rhs: open gap -> let the point close it this step; penetration -> erp push-out
-        rhs[k] = fm(-dist, dist > 0.f ? rdt : erdt, -vrel0);
-        __builtin_amdgcn_sched_barrier(0); // one point after the other: interleaved, the four points' temporaries cost three spilled registers
+        lx[k] = ly[k] = (S)0;
+        rhs[k] = gapv[k] - fm(w0x, r[k].y, fm(-w0y, r[k].x, v0z));
+        rsum += Kn[k] != (S)0 ? rhs[k] : (S)0;
     }
-    if (!any) return;
-    const float v0x = (float)v.x, v0y = (float)v.y;
-    const float mu = (float)P.friction;
-    // tangential point velocities of the pre-solve state, per point: the friction rows then need only the CHANGES
-    // dv, dw (3 fused operations per row instead of re-forming v0 + dv, w0 + dw every time)
-    float c0x[4], c0y[4];
+    const S l0 = M::max(rsum, (S)0) * M::rcp(nact * nact * im); // m * mean(rhs) / n
+    const S rest = (S)(P.mass * P.gravity * P.dt);
+    // the changes dv, dw the rows accumulate: from the start's own effect -- or, for a wave that holds a body with a LARGE start (a
+    // vote; MRS_CONTACT_BIG resting impulses: closing at ~8 m/s and beyond, a fraction of a per cent of the listed bodies), from zero,
+    // with the start applied in its symmetric form first (above); the common path carries none of that
+    S dvx = (S)0, dvy = (S)0, dvz = (S)0, dwz = (S)0;
+    S2 dwxy = {(S)0, (S)0};
+#ifndef MRS_CONTACT_BIG
+#define MRS_CONTACT_BIG 20.0f
+#endif
+    if (__builtin_amdgcn_ballot_w64(l0 > (S)MRS_CONTACT_BIG * rest) != 0) {
+        const V3 bv = v3(0., 0., (double)(nact * l0) * K.inv_mass);
+        const V3 bw = v3((double)(l0 * fm(Ixx, rsy, -(Ixy * rsx))), (double)(l0 * fm(Ixy, rsy, -(Iyy * rsx))), (double)(l0 * fm(Ixz, rsy, -(Iyz * rsx))));
+        body.add(bv, bw); // the start is in the body's float64 velocities from here on
+        v0z = (S)(v.z + bv.z); w0x = (S)(w.x + bw.x); w0y = (S)(w.y + bw.y); w0z = (S)(w.z + bw.z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ln[k] = Kn[k] != (S)0 ? l0 : (S)0;
+            rhs[k] = gapv[k] - fm(w0x, r[k].y, fm(-w0y, r[k].x, v0z));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const S l = Kn[k] != (S)0 ? l0 : (S)0;
+            ln[k] = l;
+            dvz = fm(l, im, dvz);
+            dwxy = __builtin_elementwise_fma(anxy[k], S2{l, l}, dwxy); dwz = fm(anz[k], l, dwz);
+        }
+    }
+    // the tangential point velocities of that state, per point: the friction rows then need only the CHANGES dv, dw (3 fused
+    // operations per row instead of re-forming v0 + dv, w0 + dw every time)
+    S c0x[4], c0y[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         c0x[k] = fm(w0y, r[k].z, fm(-w0z, r[k].y, v0x));
         c0y[k] = fm(w0z, r[k].x, fm(-w0x, r[k].z, v0y));
     }
-    float dvx = 0.f, dvy = 0.f, dvz = 0.f, dwz = 0.f;
-    F2 dwxy = {0.f, 0.f};
-    // Start of the sweeps (the oracle's contact_solve does the same): every active point carries the equal share of the
-    // impulse that stops the mean closing velocity, l0 = m max(sum rhs, 0) / n^2 -- exact for a body lying flat, which
-    // then needs no iteration; the sweeps correct it for everything else.  From a cold start 90 % of the grounded
-    // bodies needed 8-10 sweeps, with this start 86 % are done after the first pair (tools/probes/sweeps_probe.py).
-    {
-        float nact = 0.f, rsum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const bool a = Kn[k] != 0.f; nact += a ? 1.f : 0.f; rsum += a ? rhs[k] : 0.f; }
-        const float l0 = nact > 0.f ? fmaxf(rsum, 0.f) * __builtin_amdgcn_rcpf(nact * nact * im) : 0.f; // m * mean(rhs) / n
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float l = Kn[k] != 0.f ? l0 : 0.f;
-            ln[k] = l;
-            dvz = __builtin_fmaf(l, im, dvz);
-            dwxy = __builtin_elementwise_fma(anxy[k], F2{l, l}, dwxy); dwz = __builtin_fmaf(anz[k], l, dwz);
-        }
-    }
     // the sweeps gain ~1.5 digits each (measured on the oracle); a lane stops once a whole sweep moved no
     // impulse by more than 1e-7 of the resting impulse m g dt -- float32 cannot resolve less anyway --
     // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle).
     // Convergence is looked at on every second sweep only (the bookkeeping is ~8 % of a sweep).
-    const float tol = MRS_CONTACT_TOL * (float)(P.mass * P.gravity * P.dt) + 1e-30f;
-    auto sweep = [&](auto track, float &moved) {
+    const S tol = (S)MRS_CONTACT_TOL * rest + (S)1e-30f;
+    auto sweep = [&](auto track, S &moved) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float rx = r[k].x, ry = r[k].y, rz = r[k].z;
+            const S rx = r[k].x, ry = r[k].y, rz = r[k].z;
             { // normal: u = (ry, -rx, 0)
-                const float dvn = __builtin_fmaf(-dwxy.y, rx, __builtin_fmaf(dwxy.x, ry, dvz));
-                const float nl = fmaxf(__builtin_fmaf(Kn[k], rhs[k] - dvn, ln[k]), 0.f);
-                const float dl = nl - ln[k];
+                const S dvn = fm(-dwxy.y, rx, fm(dwxy.x, ry, dvz));
+                const S nl = M::max(fm(Kn[k], rhs[k] - dvn, ln[k]), (S)0);
+                const S dl = nl - ln[k];
                 ln[k] = nl;
-                if (track) moved = fmaxf(moved, fabsf(dl));
-                dvz = __builtin_fmaf(dl, im, dvz);
-                dwxy = __builtin_elementwise_fma(anxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(anz[k], dl, dwz);
+                if (track) moved = M::max(moved, M::abs(dl));
+                dvz = fm(dl, im, dvz);
+                dwxy = __builtin_elementwise_fma(anxy[k], S2{dl, dl}, dwxy); dwz = fm(anz[k], dl, dwz);
             }
-            const float lim = mu * ln[k];
+            const S lim = mu * ln[k];
             { // friction x: u = (0, rz, -ry)
-                const float vt = __builtin_fmaf(-dwz, ry, __builtin_fmaf(dwxy.y, rz, c0x[k] + dvx));
-                const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Kx[k], vt, lx[k]), -lim, lim); // friction pyramid: one v_med3_f32
-                const float dl = nl - lx[k];
+                const S vt = fm(-dwz, ry, fm(dwxy.y, rz, c0x[k] + dvx));
+                const S nl = M::med3(fm(-Kx[k], vt, lx[k]), -lim, lim); // friction pyramid: one v_med3_f32
+                const S dl = nl - lx[k];
                 lx[k] = nl;
-                if (track) moved = fmaxf(moved, fabsf(dl));
-                dvx = __builtin_fmaf(dl, im, dvx);
-                dwxy = __builtin_elementwise_fma(axxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(axz[k], dl, dwz);
+                if (track) moved = M::max(moved, M::abs(dl));
+                dvx = fm(dl, im, dvx);
+                dwxy = __builtin_elementwise_fma(axxy[k], S2{dl, dl}, dwxy); dwz = fm(axz[k], dl, dwz);
             }
             { // friction y: u = (-rz, 0, rx)
-                const float vt = __builtin_fmaf(-dwxy.x, rz, __builtin_fmaf(dwz, rx, c0y[k] + dvy));
-                const float nl = __builtin_amdgcn_fmed3f(__builtin_fmaf(-Ky[k], vt, ly[k]), -lim, lim);
-                const float dl = nl - ly[k];
+                const S vt = fm(-dwxy.x, rz, fm(dwz, rx, c0y[k] + dvy));
+                const S nl = M::med3(fm(-Ky[k], vt, ly[k]), -lim, lim);
+                const S dl = nl - ly[k];
                 ly[k] = nl;
-                if (track) moved = fmaxf(moved, fabsf(dl));
-                dvy = __builtin_fmaf(dl, im, dvy);
-                dwxy = __builtin_elementwise_fma(ayxy[k], F2{dl, dl}, dwxy); dwz = __builtin_fmaf(ayz[k], dl, dwz);
+                if (track) moved = M::max(moved, M::abs(dl));
+                dvy = fm(dl, im, dvy);
+                dwxy = __builtin_elementwise_fma(ayxy[k], S2{dl, dl}, dwxy); dwz = fm(ayz[k], dl, dwz);
             }
         }
     };
     int it = 0;
-    float prev_moved = 3.0e38f;
-    for (; it < P.solver_iters; it += 2) {
-        float moved = 0.f;
+    S prev_moved = (S)3.0e38f;
+    // one pair of sweeps and the stopping rule; returns true when the body is done
+    const auto sweep_pair = [&]() -> bool {
+        S moved = (S)0;
         sweep(std::false_type{}, moved);
-        if (it + 1 >= P.solver_iters) break;
+        if (it + 1 >= P.solver_iters) return true;
         sweep(std::true_type{}, moved);
 #ifdef MRS_TIMELINE // diagnostic: per lane, the first even sweep count at which it had converged
         if (diag && diag[0] == 0.f && moved <= tol) diag[0] = (float)(it + 2);
@@ -836,21 +905,26 @@ MRS_DEV void contact_solve_f32(const MrsParams &P, const Recips &K, double pz, c
         // ... of the resting impulse or of the largest impulse of this body, whichever is larger: a touchdown's impulses are
         // ~100 resting ones, and float32 sweeps cannot move them by less than 6e-8 of themselves -- measured against the
         // resting impulse alone such a body never "converges" and keeps its whole wave in the loop for all the sweeps
-        if (moved <= fmaxf(tol, MRS_CONTACT_TOL * fmaxf(fmaxf(ln[0], ln[1]), fmaxf(ln[2], ln[3])))) break;
+        if (moved <= M::max(tol, (S)MRS_CONTACT_TOL * M::max(M::max(ln[0], ln[1]), M::max(ln[2], ln[3])))) return true;
 #else
-        if (moved <= tol) break;
+        if (moved <= tol) return true;
 #endif
         // ... or once a pair of sweeps has moved the impulses by at least half of what the pair before it did: 4 % of the
         // grounded bodies never get below the tolerance (the clamps of the friction pyramid chatter), ten sweeps leave them
         // no better off than four, and each of them kept its whole wave of 64 in the loop (tools/probes/sweeps_probe.py)
-        if (moved >= MRS_CONTACT_STAG * prev_moved) break;
+        if (moved >= (S)MRS_CONTACT_STAG * prev_moved) return true;
         prev_moved = moved;
-    }
+        it += 2;
+        return !(it < P.solver_iters);
+    };
+    bool done = !(it < P.solver_iters);
+    while (!done) done = sweep_pair();
 #ifdef MRS_TIMELINE
     if (diag) diag[1] = (float)(it + 2 < P.solver_iters ? it + 2 : P.solver_iters);
 #endif
-    dv_out = F3{dvx, dvy, dvz}; dw_out = F3{dwxy.x, dwxy.y, dwz};
+    body.add(v3((double)dvx, (double)dvy, (double)dvz), v3((double)dwxy.x, (double)dwxy.y, (double)dwz));
 }
+
 
 // A body LYING FLAT AT REST on the ground (nine out of ten grounded bodies of a rollout: crashed quadcopters whose rotor
 // torques cancel) is the one case in which the sweeps of contact_solve_f32 have nothing to do: all four rim points are
@@ -933,20 +1007,15 @@ MRS_DEV bool contact_at_rest(const MrsParams &P, const Recips &K, double pz, con
     return true;
 }
 
+// the body's float64 velocities as the solvers see them: load = read them as they are now, add = apply a change
+struct ContactBodyRegs {
+    double *v, *w;
+    MRS_DEV void load(V3 &vv, V3 &ww) const { vv = v3(v[0], v[1], v[2]); ww = v3(w[0], w[1], w[2]); }
+    MRS_DEV void add(const V3 &dv, const V3 &dw) const { v[0] += dv.x; v[1] += dv.y; v[2] += dv.z; w[0] += dw.x; w[1] += dw.y; w[2] += dw.z; }
+};
 MRS_DEV void contact_stage(const MrsParams &P, const Recips &K, const double p[3], const double q[4], double v[3], double w[3])
 {
-    V3 vv = v3(v[0], v[1], v[2]), ww = v3(w[0], w[1], w[2]);
-    F3 dv, dw;
-    contact_solve_f32(P, K, p[2], q, vv, ww, dv, dw);
-    v[0] += (double)dv.x; v[1] += (double)dv.y; v[2] += (double)dv.z;
-    w[0] += (double)dw.x; w[1] += (double)dw.y; w[2] += (double)dw.z;
-}
-
-// The fused kernel's form: only the float32 velocity changes come back (see contact_solve_f32).
-MRS_DEV void contact_stage_delta(const MrsParams &P, const Recips &K, double pz, const double q[4], const double v[3], const double w[3],
-                                 F3 &dv, F3 &dw, float *diag = nullptr)
-{
-    contact_solve_f32(P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, diag);
+    contact_solve_rows<float>(P, K, p[2], q, ContactBodyRegs{v, w});
 }
 
 MRS_DEV void integrate_pose(double dt, double p[3], double q[4], const double v[3], const double w[3]);

@@ -942,12 +942,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         if (tid == 0) *ncontact = 0;
         if (n64) __syncthreads();         // visible before any wave runs ahead; taken here, before a load is in flight
     }
+    // MRS_LATE_ACT (round 5, N = 64 one-launch kernel): the launch opens with every wave of the chip asking for its actions and
+    // positions at once -- 9.4 MB that nothing can be computed beside (the wave's first arithmetic needs the positions).  The
+    // action is only needed by the NaN vote and the controller: its load rides in the pair loop like the rest of the state
+    // (MRS_LATE_LOADS) and the vote follows the loop (a NaN env has walked its pairs for nothing; its state is untouched).
+#ifndef MRS_LATE_ACT
+#define MRS_LATE_ACT 1
+#endif
+    constexpr bool late_act = MRS_LATE_ACT && MRS_LATE_LOADS && N64 && FUSED && !MRS_EXACT_F32 && ACT != MRS_ACT_NONE;
+    const float *const ap = pact + (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN * ADIM;
     if (live) {
         // Issue order = the order the data is needed in (loads return in order and the waits are counted): the
         // action (NaN vote) and the position (LDS tile, pair loop) first, so that the quaternion and the velocities
         // are still in flight while the pair loop runs instead of being waited for up front.
-        if (ACT != MRS_ACT_NONE) {
-            const float *ap = pact + (size_t)blockIdx.x * (size_t)AEPB * (size_t)AN * ADIM;
+        if (ACT != MRS_ACT_NONE && !late_act) {
 #pragma unroll
             for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
         }
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     if (n64) wave_lds_sync(); else __syncthreads();
     // MRS.py:247-248: any NaN in the env's action aborts that env's step
     bool env_nan = false;
-    if (ACT != MRS_ACT_NONE) {
+    if (ACT != MRS_ACT_NONE && !late_act) {
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < ADIM; ++k) bad |= isnan(act[k]);
@@ -1019,8 +1027,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
     }
     TL(0); // loads, tile, NaN vote
     const bool masked = live && A.mask && !A.mask[e];
-    const bool doit = live && !masked && !env_nan;
-    if (live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
+    bool doit = live && !masked && !env_nan;
+    if (!late_act && live && i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
 
     // (Round 3 experiment, removed: the waves of an env that the previous step flagged for quad-quad contact -- pair terms and a
     // second adjacency pass on top, and a launch lasts as long as its slowest workgroup -- at the top priority through every
@@ -1119,6 +1127,34 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         v[0] = wb.vel[la]; v[1] = (wb.vel + T)[la]; v[2] = (wb.vel + 2 * T)[la];
         w[0] = wb.angvel[la]; w[1] = (wb.angvel + T)[la]; w[2] = (wb.angvel + 2 * T)[la];
     }
+    if (late_act && doit) { // (no MRS_KO bit 8 here) the pair loop ahead of the NaN vote (`doit` is uniform per wave: every lane is live)
+        const int lane = tid & 63;
+        downwash_acc = downwash_ring64<false>(tile64(lds_tile, tid >> 6) + lane, (float)p[0], (float)p[1], (float)p[2], lane << 2, A.dc, [&](int j) {
+            switch (j) {
+            case 0: q[0] = wb.quat[la]; break;
+            case 1: q[1] = (wb.quat + T)[la]; break;
+            case 2: q[2] = (wb.quat + 2 * T)[la]; break;
+            case 3: q[3] = (wb.quat + 3 * T)[la]; break;
+            case 4: v[0] = wb.vel[la]; break;
+            case 5: v[1] = (wb.vel + T)[la]; break;
+            case 6: v[2] = (wb.vel + 2 * T)[la]; break;
+            case 7: w[0] = wb.angvel[la]; break;
+            case 8: w[1] = (wb.angvel + T)[la]; break;
+            case 9: w[2] = (wb.angvel + 2 * T)[la]; break;
+            case 10:
+#pragma unroll
+                for (int k = 0; k < ADIM; ++k) act[k] = ap[la * ADIM + k];
+                break;
+            default: break;
+            }
+        });
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < ADIM; ++k) bad |= isnan(act[k]);
+        env_nan = __builtin_amdgcn_ballot_w64(bad) != 0; // MRS.py:247-248; the wave is the env
+        if (i == 0 && env_nan && A.b.status) atomicOr(&A.b.status[e], MRS_STATUS_NAN_ACTION);
+        doit = !env_nan;
+    }
     if (doit) {
         V3 fb = v3(0., 0., 0.), tb = v3(0., 0., 0.);
         M3 Rb; // quat_to_matrix_bullet(q): prop heights of the ground effect, then the velocity integration
@@ -1140,7 +1176,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 // env, so the whole wave is here.)
                 const int lane = tid & 63;
                 // tile + lane: neighbour (lane + k) mod 64 at offset k, no wrap; lane << 2 = ds_bpermute byte address of this lane
-                downwash_acc = downwash_ring64<false>(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
+                if (!late_act) downwash_acc = downwash_ring64<false>(tile64(lds_tile, el) + lane, mx, my, mz, lane << 2, A.dc, [&](int j) {
 #ifdef MRS_P_DW2 // A/B: the second half of the pair loop one level down
                     if (FUSED && j == 7) __builtin_amdgcn_s_setprio(MRS_P_DW2);
 #endif
@@ -1419,6 +1455,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
             // phase: at equal priority its dependent chain advances one instruction per ~17 cycles.  Raised
             // priority lets it issue whenever it is ready.
             __builtin_amdgcn_s_setprio(MRS_P_SOLVE);
+            // the solver's view of a listed body: its float64 velocities in the LDS stash, read whenever they are wanted and changed in
+            // place (nothing float64 is live across the sweeps)
+            struct StashBody {
+                double *sp; int b;
+                __device__ __forceinline__ void load(V3 &vv, V3 &ww) const
+                {
+                    vv = v3(sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]); ww = v3(sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]);
+                }
+                __device__ __forceinline__ void add(const V3 &dv, const V3 &dw) const
+                {
+                    sp[7 * BLOCK + b] += dv.x; sp[8 * BLOCK + b] += dv.y; sp[9 * BLOCK + b] += dv.z;
+                    sp[10 * BLOCK + b] += dw.x; sp[11 * BLOCK + b] += dw.y; sp[12 * BLOCK + b] += dw.z;
+                }
+            };
             if (const int sl = tid; sl < n) { // n <= BLOCK: every lane lists at most itself
                 int seg = 0;
 #pragma unroll
@@ -1427,22 +1477,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
 #pragma unroll
                 for (int k = 0; k + 1 < NW; ++k) start = (seg == k + 1) ? wend[k] : start;
                 const int b = clist[seg * 64 + (sl - start)];
-                F3 dv, dw;
-                {
-                    const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
-                    const double vv[3] = {sp[7 * BLOCK + b], sp[8 * BLOCK + b], sp[9 * BLOCK + b]};
-                    const double ww[3] = {sp[10 * BLOCK + b], sp[11 * BLOCK + b], sp[12 * BLOCK + b]};
+                const double qq[4] = {sp[3 * BLOCK + b], sp[4 * BLOCK + b], sp[5 * BLOCK + b], sp[6 * BLOCK + b]};
+                float *dgp = nullptr;
 #ifdef MRS_TIMELINE // per-body sweep diagnostics in the pid planes 0/1 (tools/probes/sweeps_probe.py); the run's physics is void
-                    float dg[2] = {0.f, 0.f};
-                    contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw, dg);
-                    if (A.b.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
-#else
-                    contact_stage_delta(A.P, A.rc, sp[2 * BLOCK + b], qq, vv, ww, dv, dw);
+                float dg[2] = {0.f, 0.f};
+                dgp = dg;
 #endif
-                }
-                // the float64 velocities are read again from the stash: nothing float64 is live across the sweeps
-                sp[7 * BLOCK + b] += (double)dv.x; sp[8 * BLOCK + b] += (double)dv.y; sp[9 * BLOCK + b] += (double)dv.z;
-                sp[10 * BLOCK + b] += (double)dw.x; sp[11 * BLOCK + b] += (double)dw.y; sp[12 * BLOCK + b] += (double)dw.z;
+                contact_solve_rows<float>(A.P, A.rc, sp[2 * BLOCK + b], qq, StashBody{sp, b}, dgp);
+#ifdef MRS_TIMELINE
+                if (A.b.pid) wb.pid[b] = make_float4(dg[0], dg[1], 0.f, 0.f);
+#endif
             }
             __builtin_amdgcn_s_setprio(0);
             TL(5); // own share of the contact solve

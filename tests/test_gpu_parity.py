@@ -585,7 +585,12 @@ def test_one_launch_and_three_launch_steps_agree():
     (SURVEY 8d workload: a part of the swarm is on the ground by step 300).  Compared step by step from identical
     states (the three-launch shard is re-seeded from the fused one before every step: the workload is chaotic and
     would amplify rounding differences otherwise).  Not bit-identical -- the compiler contracts a*b+c per kernel --
-    so: 1e-12 relative on the float64 state, 1e-6 on the float32 controller memory/observations, adjacency equal."""
+    so: 1e-12 relative on the float64 state, 1e-6 on the float32 controller memory/observations, adjacency equal.
+    Round 5: a body that goes through the contact SWEEPS (near the ground and not finished by the closed forms) meets two
+    float32 formulations of the same rows -- four lanes per body in impulse space in the one-launch kernel (contact_solve_quad),
+    one lane per body in velocity space in k_contact (contact_solve_f32); each is held against the float64 oracle by
+    tests/test_gpu_teacher.py.  Between themselves: 2e-5 on such a body's velocities (float32 sweeps, cf. TOL_CONTACT_99), 1e-12
+    on every other body."""
     import mrsgym_amd
     E, N = 6, 64
     pos, eul = grid_spawn(E, N, seed=4)
@@ -600,6 +605,7 @@ def test_one_launch_and_three_launch_steps_agree():
         shards.append((sh, torch.zeros(E, N, sh.D, device="cuda:0"), torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0")))
     (s0, o0, a0), (s1, o1, a1) = shards
     grounded = 0
+    worst = {}
     for atype in ("set_target_vel", "set_speeds", None):
         acts = ActionStream(atype, E, N, pos, seed=9) if atype else None
         s0.set_state(pos=pos, ori=eul, vel=z, angvel=z)
@@ -607,16 +613,22 @@ def test_one_launch_and_three_launch_steps_agree():
         for t in range(300):
             a = torch.from_numpy(acts(t)).cuda() if atype else None
             s1.load_state_dict(s0.state_dict())
+            near = (s1.pos[2] <= 0.5 + 0.0613 + 0.02 + 1e-6)[None].clone()   # StepArgs.park_z: may be listed for the sweeps in this step
             for sh, obs, adj in shards:
                 sh.step(a, atype, obs_out=obs, adj_out=adj, comm_range=2.5)
             for name in ("pos", "quat", "vel", "angvel"):
                 x0, x1 = getattr(s0, name), getattr(s1, name)
-                err = float(((x0 - x1).abs() / x0.abs().clamp(min=1.0)).max())
+                rel = (x0 - x1).abs() / x0.abs().clamp(min=1.0)
+                err = float(torch.where(near.expand_as(rel), torch.zeros_like(rel), rel).max())
                 assert err < 1e-12, (atype, t, name, err)
+                err = float(rel.max())
+                assert err < (2e-5 if name in ("vel", "angvel") else 2e-7), (atype, t, name, err)
+                worst[name] = max(worst.get(name, 0.0), err)
             assert float(torch.nan_to_num(s0.pid - s1.pid, nan=0.0).abs().max()) < 1e-6 * max(1.0, float(torch.nan_to_num(s0.pid).abs().max()))
-            assert float((o0 - o1).abs().max()) < 1e-6 and torch.equal(a0, a1), (atype, t)
+            assert float((o0 - o1).abs().max()) < (2e-5 if bool(near.any()) else 1e-6) and torch.equal(a0, a1), (atype, t)
         grounded += int((s0.pos[2] < 0.52).sum())
     assert grounded > 0      # some bodies did reach the ground (z of the resting hull centre is 0.5125)
+    print("one-launch vs three-launch, worst relative difference:", worst)
 
 
 def test_full_size_bench_workload_properties():

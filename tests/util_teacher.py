@@ -64,7 +64,7 @@ def classify(pre, P, N):
 
 def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None, unconstrained=False):
     """Returns dict: err[phase] = array of per-body per-step errors (max over the 13 state words, relative above
-    magnitude 1), visited counters, adjacency mismatches (must be 0).  unconstrained=True: the oracle takes every step a
+    magnitude 1; abs_err[phase]: the same words' largest ABSOLUTE difference), visited counters, adjacency mismatches (must be 0).  unconstrained=True: the oracle takes every step a
     second time with both contact models off, and vunc[phase] holds, aligned with err[phase], the largest velocity word
     (m/s) the contact solve was handed -- what it has to cancel in float32 on the GPU."""
     c = CONFIGS[cfg]
@@ -88,6 +88,7 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
         return {k: sh.view(getattr(sh, k)).cpu().numpy() for k in ("pos", "quat", "vel", "angvel")}
 
     errs = {p: [] for p in PHASES}
+    aerrs = {p: [] for p in PHASES}
     vuncs = {p: [] for p in PHASES}
     worst = {p: (0.0, None) for p in PHASES}
     visited = dict(touchdown=0, rest=0, tumbling=0, pair=0, listed=0, nnls=0)
@@ -116,9 +117,13 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
             for k, v in keep.items():
                 getattr(sw, k)[...] = v
         e = np.zeros((E, N))
+        ea = np.zeros((E, N))                                     # the same, ABSOLUTE (north_star's metric): max |delta| over the 13 words
         for k, ref in (("pos", sw.pos), ("quat", sw.quat), ("vel", sw.vel), ("angvel", sw.angvel)):
-            e = np.maximum(e, (np.abs(post[k] - ref) / np.maximum(1.0, np.abs(ref))).max(-1))
+            d = np.abs(post[k] - ref)
+            e = np.maximum(e, (d / np.maximum(1.0, np.abs(ref))).max(-1))
+            ea = np.maximum(ea, d.max(-1))
         e = np.where(np.isfinite(e), e, np.inf)
+        ea = np.where(np.isfinite(ea), ea, np.inf)
         if dump is not None:   # diagnostic: the worst contact-phase cases with everything needed to replay them on the host
             thr = dump.get("thr", 5e-5)
             pick = (e > thr) & (ph > 0)
@@ -135,6 +140,7 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
             m = ph == i
             if m.any():
                 errs[p].append(e[m])
+                aerrs[p].append(ea[m])
                 if unconstrained:
                     vuncs[p].append(vu[m])
                 j = np.argmax(np.where(m, e, -1))
@@ -159,6 +165,7 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
             progress(t + 1)
     out = dict(cfg=cfg, E=E, N=N, steps=steps, visited=visited, adj_bad=adj_bad, worst=worst,
                err={p: (np.concatenate(errs[p]) if errs[p] else np.zeros(0)) for p in PHASES},
+               abs_err={p: (np.concatenate(aerrs[p]) if aerrs[p] else np.zeros(0)) for p in PHASES},
                vunc={p: (np.concatenate(vuncs[p]) if vuncs[p] else np.zeros(0)) for p in PHASES},
                grounded_share=float((pre["pos"][..., 2] < 0.6).mean()))
     return out

@@ -4,45 +4,24 @@
 #include <cstring>
 #include "../../mrs-gym_amd/csrc/mrs_device.hpp"
 using namespace mrs;
-// the same statements with the scalar type as a parameter (tools/host_f32/gen_variant.py)
-template <typename T> struct T3 { T x, y, z; };
-template <typename T> struct T2 { T x, y; };
-static inline float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-static inline double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <typename T> static inline T trcp(T x) { return T(1) / x; }
-template <typename T, typename U> static inline T tmax(T a, U b) { return a > (T)b ? a : (T)b; }
-template <typename T> static inline T tabs(T a) { return a < 0 ? -a : a; }
-template <typename T> static inline T tmed3(T a, T lo, T hi) { return a < lo ? lo : (a > hi ? hi : a); }
-template <typename T> static inline T2<T> tpfma(T2<T> a, T2<T> b, T2<T> c) { return T2<T>{tfma(a.x, b.x, c.x), tfma(a.y, b.y, c.y)}; }
-namespace mrs {
-#include "contact_variant.inc"
-#include "contact_split.inc"
-}
-#define VARIANT(NAME, CTT, STT) extern "C" void NAME(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw) { \
-    Recips K{}; K.inv_mass = 1.0 / P->mass; K.inv_i0 = 1.0 / P->inertia[0]; K.inv_i1 = 1.0 / P->inertia[1]; K.inv_i2 = 1.0 / P->inertia[2]; K.inv_dt = 1.0 / P->dt; \
-    contact_solve_split<CTT, STT>(*P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, 0); }
-VARIANT(host_setup64_sweeps32, double, float)
-VARIANT(host_setup32_sweeps64, float, double)
-VARIANT(host_setup32_sweeps32, float, float)
-extern "C" void host_contact_f64(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw)
+// the same statements with the scalar type as a parameter: mrs_device.hpp contact_solve_rows<S> (a template since round 5; rounds 3-4
+// derived the float64 text by regular expressions).  dv[2] carries the start's float64 share as well.
+template <class S>
+static void rows(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw)
 {
     Recips K{};
     K.inv_mass = 1.0 / P->mass; K.inv_i0 = 1.0 / P->inertia[0]; K.inv_i1 = 1.0 / P->inertia[1]; K.inv_i2 = 1.0 / P->inertia[2]; K.inv_dt = 1.0 / P->dt;
-    contact_solve_t<double, double>(*P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, 0);
+    double vv[3] = {v[0], v[1], v[2]}, ww[3] = {w[0], w[1], w[2]};
+    contact_solve_rows<S>(*P, K, pz, q, ContactBodyRegs{vv, ww});
+    for (int i = 0; i < 3; ++i) { dv[i] = vv[i] - v[i]; dw[i] = ww[i] - w[i]; }
 }
-extern "C" void host_contact_f32t(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw)
-{
-    Recips K{};
-    K.inv_mass = 1.0 / P->mass; K.inv_i0 = 1.0 / P->inertia[0]; K.inv_i1 = 1.0 / P->inertia[1]; K.inv_i2 = 1.0 / P->inertia[2]; K.inv_dt = 1.0 / P->dt;
-    contact_solve_t<float, float>(*P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), dv, dw, 0);
-}
+extern "C" void host_contact_f64(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw) { rows<double>(P, pz, q, v, w, dv, dw); }
+extern "C" void host_contact_f32t(const MrsParams *P, double pz, const double *q, const double *v, const double *w, double *dv, double *dw) { rows<float>(P, pz, q, v, w, dv, dw); }
 extern "C" void host_contact(const MrsParams *P, double pz, const double *q, const double *v, const double *w, float *dv, float *dw)
 {
-    Recips K{};
-    K.inv_mass = 1.0 / P->mass; K.inv_i0 = 1.0 / P->inertia[0]; K.inv_i1 = 1.0 / P->inertia[1]; K.inv_i2 = 1.0 / P->inertia[2]; K.inv_dt = 1.0 / P->dt;
-    F3 a, b;
-    contact_solve_f32(*P, K, pz, q, v3(v[0], v[1], v[2]), v3(w[0], w[1], w[2]), a, b);
-    dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dw[0] = b.x; dw[1] = b.y; dw[2] = b.z;
+    double a[3], b[3];
+    rows<float>(P, pz, q, v, w, a, b);
+    for (int i = 0; i < 3; ++i) { dv[i] = (float)a[i]; dw[i] = (float)b[i]; }
 }
 
 // One body through the step kernel's rigid-body pipeline (mrs_kernels.hip k_step: integrate_velocity -> contact_at_rest |

@@ -13,7 +13,7 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                        "-S", "--cuda-device-only", os.path.join(ROOT, "mrs-gym_amd/csrc/mrs_kernels.hip"), "-o", out] + flags,
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()
-m = re.search(r"^_Z6k_stepILi4ELi256ELb1EEv8StepArgs:.*?s_endpgm", txt, re.S | re.M)
+m = re.search(r"^_Z6k_stepILi4ELi256ELb1ELb1EEviiiiPKfPKdS3_S3_S3_8StepArgs:.*?s_endpgm", txt, re.S | re.M)
 body = m.group(0).split("\n")
 names = {"0": "downwash pairs", "1": "vel/pos control", "20": "read-back + R", "21": "attitude ctrl", "2": "forces/gnd/drag", "22": "integrate vel",
          "3": "stash+ballot", "4": "contact solve", "5": "(after solve)", "6": "pose+store", "7": "obs+adjacency", "8": "end"}

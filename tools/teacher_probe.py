@@ -45,8 +45,9 @@ def main():
         for ph in ut.PHASES:
             q = ut.quantiles(r["err"][ph])
             if q:
-                print("   %-7s n=%9d  50%% %.2e  99%% %.2e  99.9%% %.2e  max %.2e  at (t, env, agent) %s"
-                      % (ph, q["n"], q["q50"], q["q99"], q["q999"], q["max"], r["worst"][ph][1]))
+                qa = ut.quantiles(r["abs_err"][ph])
+                print("   %-7s n=%9d  50%% %.2e  99%% %.2e  99.9%% %.2e  max %.2e  at (t, env, agent) %s   ABSOLUTE: 99%% %.2e  99.9%% %.2e  max %.2e"
+                      % (ph, q["n"], q["q50"], q["q99"], q["q999"], q["max"], r["worst"][ph][1], qa["q99"], qa["q999"], qa["max"]))
                 if ph != "free":        # split by what the contact solve was handed (the oracle's unconstrained velocity, largest word)
                     import numpy as np
                     x, vu = r["err"][ph], r["vunc"][ph]
