@@ -186,6 +186,24 @@ def main():
                 scratch.step(table[0])
             torch.cuda.synchronize()
     gather = mdist.ObsAllGather(E, N, 6, dev) if world > 1 else None
+    # What the collective layer saw: gathered once, before anything is timed, so that a scaling run can be checked
+    # for "RCCL saw N ranks, one device each" from the JSON line alone.
+    comm_info = None
+    if world > 1:
+        try:
+            mine = {"rank": rank, "device": str(dev), "device_name": torch.cuda.get_device_name(dev), "pid": os.getpid(),
+                    "visible_devices": torch.cuda.device_count()}
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as exc:   # noqa: BLE001
+                ver = "unavailable (%s)" % type(exc).__name__
+            comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_devices": [e["device"] for e in everyone],
+                         "ranks": everyone, "rccl_version": ver, "distinct_devices": len({e["device"] for e in everyone}),
+                         "obs_allgather_mode": gather.mode, "single_device_rehearsal": single}
+        except Exception as exc:       # noqa: BLE001 -- reported, never fatal
+            comm_info = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # HIP events on the stream the step kernels are launched on (torch's current stream) bracket SPANS of
     # EV_SPAN consecutive mrs_step launches, one span every EV_EVERY steps: on this stack a timing-event pair
     # costs the stream ~60 us (measured 137 us per step with a pair on every step against 76 us with none),
@@ -207,12 +225,15 @@ def main():
             env.step(table[t // 50])
         return (env.shard.pos[2] < 0.6).float().mean()
 
-    def timed_region(env, t_first, with_gather):
-        """W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier; max over ranks."""
+    def timed_region(env, t_first, with_gather, read_A=False):
+        """W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier; max over ranks.
+        read_A: the consumer looks at info["A"] every step (A_FORMAT = "dense" materialises the float32 stack only for one that does)."""
         shard_step = env.shard.step_ptr
 
         def one_step(t):
-            env.step(table[t // 50])
+            out = env.step(table[t // 50])
+            if read_A:
+                out[3]["A"].materialize()
             if with_gather:
                 gather.gather(env._Xring.newest())
         # everything the timed loop needs exists before the warm-up, so that nothing but the barrier + synchronize
@@ -289,17 +310,26 @@ def main():
     extra = {}
     if world == 1:
         # `value`: the step itself -- one GPU, nothing to exchange
-        elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, False)
+        elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, False, read_A=args.dense_a)
         if not args.no_dense_a and not args.dense_a:
             # the reference's return format: float32 0/1 (E,K+1,N,N) adjacency materialised every step (a second launch)
             del env
             denv = make_env("dense")
             warm(min(prewarm_s, 0.3))
             rollin(denv)
-            d_elapsed, _, _ = timed_region(denv, args.rollin, False)
+            d_elapsed, _, _ = timed_region(denv, args.rollin, False, read_A=True)
             extra["dense_a"] = {"value": agent_steps / d_elapsed, "unit": "agent-steps/s", "ms_per_step": d_elapsed / args.steps * 1e3,
                                 "what": "same K steps with info['A'] as the dense float32 (E,K+1,N,N) tensor the reference returns "
-                                        "(516 B per agent-step algorithmic, SURVEY.md 8d) instead of bit-packed rows"}
+                                        "(516 B per agent-step algorithmic, SURVEY.md 8d) instead of bit-packed rows, READ every step"}
+            # the library's default construction (A_FORMAT = "dense") in a loop that never looks at info["A"]: the float32 stack is
+            # materialised on first use only (mrsgym_amd/lazy.py), so this must cost what the packed rows cost
+            del denv
+            denv = make_env("dense")          # a fresh one: nobody has ever looked at its info["A"]
+            warm(min(prewarm_s, 0.3))
+            rollin(denv)
+            u_elapsed, _, _ = timed_region(denv, args.rollin, False, read_A=False)
+            extra["dense_a_unread"] = {"value": agent_steps / u_elapsed, "unit": "agent-steps/s", "ms_per_step": u_elapsed / args.steps * 1e3,
+                                       "what": "A_FORMAT='dense' (the default), info['A'] never touched: packed rows only, the float32 stack is lazy"}
             del denv
         if not args.no_model_legs and not args.dense_a:
             # The headline must not hang on the fidelity knobs: the same K steps with every knob at its literal
@@ -440,6 +470,8 @@ def main():
                      "counters_from": prof_src},
     }
     out.update(extra)
+    if comm_info is not None:
+        out["comm"] = comm_info
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline()
         # the literal reference cannot run here (pybullet absent); its Python controller alone

@@ -816,31 +816,21 @@ MRS_DEV void contact_solve_rows(const MrsParams &P, const Recips &K, double pz, 
     }
     const S l0 = M::max(rsum, (S)0) * M::rcp(nact * nact * im); // m * mean(rhs) / n
     const S rest = (S)(P.mass * P.gravity * P.dt);
-    // the changes dv, dw the rows accumulate: from the start's own effect -- or, for a wave that holds a body with a LARGE start (a
-    // vote; MRS_CONTACT_BIG resting impulses: closing at ~8 m/s and beyond, a fraction of a per cent of the listed bodies), from zero,
-    // with the start applied in its symmetric form first (above); the common path carries none of that
+    // the start's effect goes into the body's float64 velocities now, in its symmetric form (above); the changes dv, dw the rows
+    // accumulate start from zero.  (For every body alike: choosing per body by the size of the start -- built -- saves the common
+    // path ~50 instructions but makes a body's roundings depend on a threshold, and the few bodies whose sweeps do not converge
+    // amplify any such difference; a wave vote on it would make results depend on which bodies share a wave.)
     S dvx = (S)0, dvy = (S)0, dvz = (S)0, dwz = (S)0;
     S2 dwxy = {(S)0, (S)0};
-#ifndef MRS_CONTACT_BIG
-#define MRS_CONTACT_BIG 20.0f
-#endif
-    if (__builtin_amdgcn_ballot_w64(l0 > (S)MRS_CONTACT_BIG * rest) != 0) {
+    {
         const V3 bv = v3(0., 0., (double)(nact * l0) * K.inv_mass);
         const V3 bw = v3((double)(l0 * fm(Ixx, rsy, -(Ixy * rsx))), (double)(l0 * fm(Ixy, rsy, -(Iyy * rsx))), (double)(l0 * fm(Ixz, rsy, -(Iyz * rsx))));
-        body.add(bv, bw); // the start is in the body's float64 velocities from here on
+        body.add(bv, bw);
         v0z = (S)(v.z + bv.z); w0x = (S)(w.x + bw.x); w0y = (S)(w.y + bw.y); w0z = (S)(w.z + bw.z);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             ln[k] = Kn[k] != (S)0 ? l0 : (S)0;
             rhs[k] = gapv[k] - fm(w0x, r[k].y, fm(-w0y, r[k].x, v0z));
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const S l = Kn[k] != (S)0 ? l0 : (S)0;
-            ln[k] = l;
-            dvz = fm(l, im, dvz);
-            dwxy = __builtin_elementwise_fma(anxy[k], S2{l, l}, dwxy); dwz = fm(anz[k], l, dwz);
         }
     }
     // the tangential point velocities of that state, per point: the friction rows then need only the CHANGES dv, dw (3 fused

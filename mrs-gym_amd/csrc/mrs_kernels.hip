@@ -1904,6 +1904,7 @@ struct MrsHandle {
     int *pair_flag;     // device workspace [E]: quad-quad contact candidates per env (StepArgs.pair_flag); all ones = "look"
     unsigned long long *pair_rows; // device workspace [T][W]: the candidates per agent (StepArgs.pair_rows)
     bool big_lds[MRS_ACT_TARGET_ORI + 1]; // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device, per ACTION_TYPE
+    bool raycast_big_lds = false; // k_raycast's dynamic-LDS attribute raised on this device (N >= 683)
     // The part of StepArgs that only depends on the parameters, the observation spec and the range (fill_common): kept from one
     // call to the next -- a step of a small swarm (C2: 12 us of kernel) is host-bound, and the threshold search, the logarithm and
     // the divisions of fill_common were ~0.4 us of every call.  Invalidated by mrs_set_params.

@@ -524,8 +524,15 @@ extern "C" int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offse
     S.b = *b; S.offset = offset; S.dirs = directions; S.hit = hit_obj; S.pos_world = pos_world; S.pos_body = pos_body; S.dist = dist;
     S.E = h->E; S.N = h->N; S.R = n_rays; S.body = body; S.range = range;
     S.rc = h->P.coll_radius; S.hl = h->P.coll_half_len; S.ground_z = h->P.ground_z; S.T = (size_t)h->E * h->N;
-    if ((size_t)h->N * (6 * sizeof(double) + 12 * sizeof(float)) > 64 * 1024) return fail(MRS_E_ARG, "mrs_raycast: n_agents too large for one workgroup's LDS");
-    hipLaunchKernelGGL(mrs_sense::k_raycast, dim3(h->E), dim3(256), (size_t)h->N * (6 * sizeof(double) + 12 * sizeof(float)), (hipStream_t)stream, S);
+    // 96 bytes of LDS per agent: above 64 KB (N >= 683; mrs_create takes N up to 1024 = 96 KB of the CU's 160) the launch needs the
+    // function attribute raised, once per handle = per device (the guard that stood here refused what used to run)
+    const size_t lds = (size_t)h->N * (6 * sizeof(double) + 12 * sizeof(float));
+    if (lds > 64 * 1024 && !h->raycast_big_lds) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&mrs_sense::k_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return hipfail(ea, "mrs_raycast: raising the LDS limit");
+        h->raycast_big_lds = true;
+    }
+    hipLaunchKernelGGL(mrs_sense::k_raycast, dim3(h->E), dim3(256), lds, (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_raycast launch");
 }

@@ -99,15 +99,18 @@ class ObsAllGather:
         """The one-shot form: this rank's slice to every peer, every peer's slice into its place in `out` -- one grouped batch."""
         me = self.rank
         out[self.offsets[me]:self.offsets[me] + self.sizes[me]].copy_(src)
+        # P2POp's `peer` is a GLOBAL rank; r indexes sizes / offsets by the rank inside self.group (ADVICE r4: with a sub-group
+        # the sends and receives would otherwise address the wrong processes)
+        peer = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
         ops = []
         for r in range(self.world):
             if r == me or self.sizes[r] == 0:
                 continue
-            ops.append(dist.P2POp(dist.irecv, out[self.offsets[r]:self.offsets[r] + self.sizes[r]], r, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, out[self.offsets[r]:self.offsets[r] + self.sizes[r]], peer(r), group=self.group))
         if self.sizes[me] > 0:
             for r in range(self.world):
                 if r != me:
-                    ops.append(dist.P2POp(dist.isend, src, r, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, src, peer(r), group=self.group))
         return dist.batch_isend_irecv(ops) if ops else []
 
     def gather(self, newest):

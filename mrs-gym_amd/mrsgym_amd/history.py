@@ -38,6 +38,7 @@ class HistoryRing:
         """deque([]) (MRS.py:185-186)."""
         self.head = self.L - (self.K + 1)
         self.count = 0
+        self.wraps = getattr(self, "wraps", 0) + 2      # every window handed out so far is gone (see intact())
         if self.pad == "zero":
             self.buf[self.head:].zero_()
 
@@ -49,9 +50,16 @@ class HistoryRing:
                 if self.K > 0:
                     self.buf[new_head + 1:new_head + 1 + self.K].copy_(self.buf[0:self.K])   # L >= 2(K+1): no overlap
                 self.head = new_head
+                self.wraps += 1
             else:
                 self.head -= 1
         return self.head
+
+    def intact(self, head, wraps):
+        """Do the slots [head, head + K] still hold what they held when the window stood there (at wrap count `wraps`)?  New slices
+        are written below the head, so nothing up there changes until the head wraps; after ONE wrap the copied slices sit in the
+        top K slots and the new head descends from L - K - 1: intact while it has not reached the old window."""
+        return self.wraps == wraps or (self.wraps == wraps + 1 and head + self.K < self.head)
 
     def ptr(self, slot):
         return self._base + slot * self._stride

@@ -17,6 +17,7 @@ import torch
 from . import native
 from .facade import Environment, QuadView, StateFnCompiler
 from .history import HistoryRing
+from .lazy import LazyDenseA
 
 try:  # gym / gymnasium are optional (absent in the build image)
     import gym as _gym  # type: ignore
@@ -178,10 +179,13 @@ class MRS(_EnvBase):
         self._Xring = None            # allocated once D is known (StateFnCompiler)
         self._Apacked = HistoryRing(self.K_HOPS, (E, N, W), torch.int64, self.device, self.HISTORY_SLOTS, pad="zero",
                                     view_fn=self._stack_view)
+        # A_FORMAT = "dense": the float32 ring exists (and is written by the step kernel) only while info["A"] is being READ
+        # (lazy.LazyDenseA, _materialize_A): allocated at the first read, dropped back to packed-only after DENSE_IDLE_STEPS
+        # steps without one
         self._Adense = None
-        if self.A_FORMAT == "dense":
-            self._Adense = HistoryRing(self.K_HOPS, (E, N, N), torch.float32, self.device, self.HISTORY_SLOTS, pad="zero",
-                                       view_fn=self._stack_view)
+        self._dense_live = False
+        self._dense_read_step = -(1 << 60)
+        self._a_stamp = 0             # counts the changes of the adjacency window: a LazyDenseA knows whether it is still the current one
 
     def _ensure_xbuf(self, D):
         if self._Xring is None or self._Xring.buf.shape[-1] != D:
@@ -203,24 +207,65 @@ class MRS(_EnvBase):
     def get_Xk(self):  # MRS.py:98-99  Xk: K+1 x N x D  (E x K+1 x N x D)
         return self._out(self._Xring.view())
 
+    DENSE_IDLE_STEPS = 64
+
     def calc_Ak(self):  # MRS.py:102-110
         slot = self._Apacked.next_slot()
-        dslot = self._Adense.next_slot() if self._Adense is not None else 0
-        self.shard.adjacency(self._Apacked.buf[slot], self.COMM_RANGE, self._Adense.buf[dslot] if self._Adense is not None else None)
+        dr = self._Adense if self._dense_live else None
+        dslot = dr.next_slot() if dr is not None else 0
+        self.shard.adjacency(self._Apacked.buf[slot], self.COMM_RANGE, dr.buf[dslot] if dr is not None else None)
         self._Apacked.committed()
-        if self._Adense is not None:
-            self._Adense.committed()
+        if dr is not None:
+            dr.committed()
+        self._a_stamp += 1
         return self.get_Ak()
 
     def _expand_newest_A(self):
-        if self._Adense is not None:
+        if self._dense_live:
             slot = self._Adense.next_slot()
             self.shard.adjacency_expand(self._Apacked.newest(), self._Adense.buf[slot])
             self._Adense.committed()
 
+    def _activate_dense(self):
+        """First read of info["A"] (or the first one after an idle stretch): the dense ring takes over the packed ring's position and
+        its K+1 current slices -- one mrs_adjacency_expand over the window -- and the step kernel writes it from here on."""
+        ar = self._Apacked
+        if self._Adense is None:
+            E, N = self.N_ENVS, self.N_AGENTS
+            self._Adense = HistoryRing(self.K_HOPS, (E, N, N), torch.float32, self.device, ar.L, pad="zero", view_fn=self._stack_view)
+        dr = self._Adense
+        dr.head, dr.count = ar.head, ar.count
+        self.shard.adjacency_expand(ar.window().contiguous(), dr.window().view(-1, self.N_AGENTS, self.N_AGENTS))
+        self._dense_live = True
+
+    def _materialize_A(self, stamp, saved):
+        """The float32 stack behind a LazyDenseA made at window change number `stamp` (saved: a clone of the packed window it
+        stood for, kept when outputs are copies; the window's position in the ring when they are views)."""
+        if stamp == self._a_stamp:
+            if not self._dense_live:
+                self._activate_dense()
+            self._dense_read_step = self._global_step
+            return self._out(self._Adense.view())
+        # an older stack, read late (the reference's loops do: DataGenerator.py logs the previous A after the step): from its own packed
+        # rows -- the clone it kept (outputs are copies), or the ring slots it stood for as long as they have not been reused (views)
+        if isinstance(saved, tuple):
+            ar, (head, wraps) = self._Apacked, saved
+            if not ar.intact(head, wraps):
+                raise RuntimeError("info['A'] of an earlier step was first read after its history slots had been reused (outputs are views: "
+                                   "N_ENVS > 1, COPY_OUTPUTS unset): read it within HISTORY_SLOTS - 2 (K_HOPS + 1) steps, or pass COPY_OUTPUTS=True")
+            saved = ar.buf[head:head + ar.K + 1]
+        K1, E, N = saved.shape[0], self.N_ENVS, self.N_AGENTS
+        dense = torch.empty(K1, E, N, N, dtype=torch.float32, device=self.device)
+        self.shard.adjacency_expand(saved, dense.view(-1, N, N))
+        return self._stack_view(dense)
+
     def get_Ak(self):  # MRS.py:113-114  Ak: K+1 x N x N, missing slots are zeros (MRS.py:107-108)
-        ring = self._Adense if self._Adense is not None else self._Apacked
-        return self._out(ring.view())
+        if self.A_FORMAT != "dense":
+            return self._out(self._Apacked.view())
+        stamp = self._a_stamp
+        saved = self._Apacked.window().clone() if self._copies() else (self._Apacked.head, self._Apacked.wraps)
+        E, K1, N = self.N_ENVS, self.K_HOPS + 1, self.N_AGENTS
+        return LazyDenseA(lambda: self._materialize_A(stamp, saved), (K1, N, N) if E == 1 else (E, K1, N, N), self.device)
 
     def calc_A(self):  # MRS.py:117-124  newest adjacency only, no history side effect
         E, N, W = self.N_ENVS, self.N_AGENTS, self.shard.W
@@ -233,9 +278,10 @@ class MRS(_EnvBase):
         return self._squeeze(dense)
 
     def _clear_history(self):  # self.X = deque([]); self.A = deque([])  (MRS.py:185-186)
-        for r in (self._Xring, self._Apacked, self._Adense):
+        for r in (self._Xring, self._Apacked, self._Adense if self._dense_live else None):
             if r is not None:
                 r.clear()
+        self._a_stamp += 1
 
     # ------------------------------------------------------------------ spawn
     def default_spawn_dist(self):  # MRS.py:69-78 (the torch.distributions object, for callers that want it)
@@ -478,9 +524,10 @@ class MRS(_EnvBase):
         if self.K_HOPS > 0:
             w = xr.window()
             w[1:, mask] = w[0, mask]
-        for ring in (self._Apacked, self._Adense):
+        for ring in (self._Apacked, self._Adense if self._dense_live else None):
             if ring is not None:
                 ring.window()[:, mask] = 0
+        self._a_stamp += 1
         Xk = self.get_Xk()
         self.last_obs = Xk
         return Xk
@@ -582,7 +629,9 @@ class MRS(_EnvBase):
         xr, ar = self._Xring, self._Apacked
         xslot = xr.next_slot()
         aslot = ar.next_slot() if want_A else 0
-        dr = self._Adense if want_A else None       # A_FORMAT = "dense": the float32 matrices come out of the same launch
+        if self._dense_live and self._global_step - self._dense_read_step > self.DENSE_IDLE_STEPS:
+            self._dense_live = False                # nobody has looked at info["A"] for a while: packed rows only again
+        dr = self._Adense if (want_A and self._dense_live) else None   # A_FORMAT = "dense", being read: the float32 matrices come out of the same launch
         dslot = dr.next_slot() if dr is not None else 0
         self.shard.step_ptr(actions, at, xr.ptr(xslot) if fused else 0, ar.ptr(aslot) if want_A else 0,
                             float(self.COMM_RANGE), dr.ptr(dslot) if dr is not None else 0)
@@ -595,6 +644,7 @@ class MRS(_EnvBase):
             ar.committed()
             if dr is not None:
                 dr.committed()
+            self._a_stamp += 1
             Ak = self.get_Ak()
         if (self._global_step & 255) == 255 and (self.CHECK_NAN or ("sync" if E == 1 else "lazy")) == "lazy":   # _global_step: never zeroed by reset()
             self._poll_errors()
@@ -704,6 +754,7 @@ class MRS(_EnvBase):
             done += cnt
         self.steps_since_reset += n
         self._global_step += n
+        self._a_stamp += 1
 
     def get_env(self):  # MRS.py:280-293
         return self.env

@@ -291,6 +291,71 @@ def test_reference_mrs_step_outputs(path):
         assert r == d["reward"][t] and dn == bool(d["done"][t])
 
 
+def test_default_dense_A_is_lazy_and_identical():
+    """the default construction (A_FORMAT = "dense") returns info["A"] as a torch.Tensor of the reference's shape and
+    dtype that is materialised on first use (mrsgym_amd/lazy.py).  (a) read every step it equals the expansion of the packed rows of
+    a twin environment bit for bit (K_HOPS history, zero padding after reset, a masked reset in between); (b) never read, no float32
+    ring exists at all; (c) read once, the step kernel keeps the ring current until nobody has looked for DENSE_IDLE_STEPS steps; (d) a
+    stack read late comes from its own rows: the clone it kept (copies, N_ENVS = 1) or its ring slots while they last (views; an error after)."""
+    import mrsgym_amd
+    from mrsgym_amd.lazy import LazyDenseA
+    E, N, K = 3, 64, 2
+    pos, _ = grid_spawn(E, N, seed=11)
+    acts = ActionStream("set_target_vel", E, N, pos, seed=12)
+
+    def mk(fmt, **kw):
+        env = mrsgym_amd.make('mrs-v0', N_ENVS=E, N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.0, ACTION_TYPE="set_target_vel",
+                              START_POS=torch.from_numpy(pos), HEADLESS=True, A_FORMAT=fmt, **kw)
+        env.reset(ori=torch.zeros(E, N, 3))      # (the default START_ORI draws a yaw per agent: the twins must start alike)
+        return env
+
+    def expand(env, packed):            # (E, K+1, N, W) int64 -> (E, K+1, N, N) float32
+        p = packed.contiguous()
+        out = torch.empty(p.shape[0] * p.shape[1], N, N, device=p.device)
+        env.shard.adjacency_expand(p.view(-1, N, p.shape[-1]), out)
+        return out.view(p.shape[0], p.shape[1], N, N)
+
+    dense, packed, unread = mk("dense"), mk("packed"), mk("dense")
+    for t in range(40):
+        a = torch.from_numpy(acts(t)).cuda()
+        if t == 17:
+            m = torch.tensor([True, False, True], device="cuda")
+            for env in (dense, packed, unread):
+                env.reset_envs(m, ori=torch.zeros(E, N, 3))
+        A = dense.step(a)[3]["A"]
+        Ap = packed.step(a)[3]["A"]
+        unread.step(a)
+        assert isinstance(A, torch.Tensor) and isinstance(A, LazyDenseA) and A.shape == (E, K + 1, N, N) and A.dtype == torch.float32 and A.device.type == "cuda"
+        assert torch.equal(A, expand(packed, Ap)), t                       # (a)
+    assert unread._Adense is None and not unread._dense_live                # (b)
+    assert dense._dense_live
+    for t in range(40, 40 + dense.DENSE_IDLE_STEPS + 3):                    # (c)
+        a = torch.from_numpy(acts(t)).cuda()
+        last = dense.step(a)[3]["A"]
+        packed.step(a)
+    assert not dense._dense_live
+    assert torch.equal(last.materialize(), expand(packed, packed.get_Ak())) and dense._dense_live   # ... and comes back on the next read
+    a0 = torch.from_numpy(acts(0)).cuda()
+    stale = dense.step(a0)[3]["A"]                                           # (d) views: a stack first read after the env has moved on ...
+    stale_p = packed.step(a0)[3]["A"].clone()
+    dense.step(a0); packed.step(a0)
+    assert torch.equal(stale, expand(packed, stale_p))                        # ... still stands for its own step (the reference's data loops log the previous A)
+    gone = dense.step(a0)[3]["A"]
+    for _ in range(dense._Apacked.L):                                         # ... until its ring slots have been reused
+        dense.step(a0)
+    with pytest.raises(RuntimeError):
+        gone.sum()
+    one = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.0, START_POS=torch.from_numpy(pos[0]), HEADLESS=True)
+    one.reset(ori=torch.zeros(N, 3))
+    ref = mrsgym_amd.make('mrs-v0', N_AGENTS=N, state_fn=state_fn, K_HOPS=K, COMM_RANGE=2.0, START_POS=torch.from_numpy(pos[0]), HEADLESS=True, A_FORMAT="packed")
+    ref.reset(ori=torch.zeros(N, 3))
+    a1 = torch.from_numpy(acts(0)[0])
+    old = one.step(a1)[3]["A"]
+    oldp = ref.step(a1)[3]["A"]
+    one.step(a1); ref.step(a1)
+    assert old.shape == (K + 1, N, N) and torch.equal(old, expand(ref, oldp[None])[0])      # copies: its own rows, whatever happened since
+
+
 def test_vectorised_envs_match_single_env_runs():
     """N_ENVS = E adds a leading axis and nothing else: env e of the batch == a single-env run of env e."""
     import mrsgym_amd
@@ -614,6 +679,11 @@ def test_bench_contract_single_and_two_ranks():
     # gathered every k-th step only: first-class legs; the one-shot form needs RCCL (one device per rank) and says so here
     assert d2["gather_every_4"]["value"] > 0 and d2["gather_every_16"]["value"] > 0
     assert d2["direct_p2p"]["value"] is None and "nccl" in d2["direct_p2p"]["error"]
+    # what the collective layer saw, from the JSON line alone: here two gloo ranks rehearsing on ONE device
+    c = d2["comm"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and len(c["rank_devices"]) == 2 and [r["rank"] for r in c["ranks"]] == [0, 1]
+    assert c["distinct_devices"] == 1 and c["single_device_rehearsal"] is True and c["rccl_version"]
+    assert "comm" not in d
 
 
 def test_handle_on_a_device_that_is_not_the_current_one():

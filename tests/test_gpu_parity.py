@@ -553,6 +553,43 @@ def test_spawn_rejection_matches_reference_replay_F5b(golden_dir):
         assert np.array_equal(sh1.view(sh1.pos).cpu().numpy()[0], d[group[e_long] + "_final"].astype(np.float64))
 
 
+@pytest.mark.parametrize("N", [100, 192])
+def test_spawn_rejection_across_waves_matches_the_pinned_restatement(N):
+    """k_spawn's greedy picks at N > 64 run across the waves of the workgroup (per-wave maxima exchanged through LDS, a
+    barrier inside the pick loop); F5b (the reference's own rejection loop) pins N = 3, 12, 32 only.  Here the GPU is held bit for
+    bit against oracle.spawn_from -- the restatement F5b pins (tests/test_oracle_golden.py) -- at N = 100 and 192 on crowded
+    candidate rounds, with collision-count ties planted ACROSS waves (agents 5 and 70 sit on the same spot as two others each:
+    equal counts, the lower index must go first, MRS.py:140-144 torch.mode), and through the SPAWN_MORE / resume round trip."""
+    import mrsgym_amd
+    rng = np.random.default_rng(N)
+    E, R = 6, 40
+    cand = np.zeros((E, R, N, 3), np.float32)
+    for e in range(E):
+        spread = 3.5 * (1.0, 1.3, 1.7, 1.0, 1.3, 1.7)[e] * np.sqrt(N / 64.0)     # crowded: 5 ... 32 rounds until every agent has its 0.6 m
+        cand[e] = rng.uniform(-spread, spread, (R, N, 3)).astype(np.float32)
+        cand[e, :, :, 2] = rng.uniform(1.0, 1.5, (R, N)).astype(np.float32)
+        # planted ties across waves in the first round: 5 and 70 each share a spot with two partners further up
+        cand[e, 0, 80] = cand[e, 0, 81] = cand[e, 0, 5]
+        cand[e, 0, 90] = cand[e, 0, 91] = cand[e, 0, 70]
+    want, used = zip(*(oracle.spawn_from(cand[e], 0.3) for e in range(E)))
+    assert max(used) > 2 and min(used) > 0, used            # crowded enough to need several rounds, and every env settles
+    sh = mrsgym_amd.SwarmShard(E, N, "cuda:0")
+    sh.spawn_from(torch.from_numpy(cand).cuda(), agent_radius=0.3)
+    assert int(sh.status.cpu().sum()) == 0
+    got = sh.view(sh.pos).cpu().numpy()
+    for e in range(E):
+        assert np.array_equal(got[e], want[e].astype(np.float64)), (N, e, used[e])
+    # one round short -> MRS_STATUS_SPAWN_MORE; resumed with the rest -> the same layout
+    e = int(np.argmax(used))
+    sh1 = mrsgym_amd.SwarmShard(1, N, "cuda:0")
+    sh1.spawn_from(torch.from_numpy(cand[e:e + 1, :used[e] - 1]).cuda(), agent_radius=0.3)
+    assert int(sh1.status.cpu()[0]) & 4
+    sh1.status.zero_()
+    sh1.spawn_from(torch.from_numpy(cand[e:e + 1, used[e] - 1:]).cuda(), agent_radius=0.3, resume=True)
+    assert int(sh1.status.cpu()[0]) == 0
+    assert np.array_equal(sh1.view(sh1.pos).cpu().numpy()[0], want[e].astype(np.float64))
+
+
 def test_env_sharding_is_bitwise():
     """E envs on one shard == the same envs split over two shards (multi-GPU correctness)."""
     import mrsgym_amd

@@ -26,7 +26,7 @@ def _shard(pos, quat):
     return sh
 
 
-@pytest.mark.parametrize("E,N", [(3, 5), (2, 64), (1, 1), (2, 130)])
+@pytest.mark.parametrize("E,N", [(3, 5), (2, 64), (1, 1), (2, 130), (1, 1024)])   # N = 1024: 96 KB of LDS, above the launch's default limit
 def test_raycast_matches_oracle(E, N):
     rng = np.random.default_rng(E * 100 + N)
     pos, quat = _scene(rng, E, N, spread=0.3 if N < 20 else 1.5)
