@@ -723,11 +723,21 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
     float trav = 0.f;
     double dkeep = 0.;
     const auto mag2 = [&](f2 d2, f2 rz) { return downwash_mag2_pk(d2, rz, dr); };
+    // (Round 5 experiment, removed: the two selects per pair as integer masks -- (0 - bits) >> 31, ands, v_bitop3 -- instead of
+    // v_cmp + s_and + v_cndmask: bit-identical, 7 compares left of 164 in the loop, and 0.9 us per step SLOWER at 4096 envs.)
     const auto mine_of = [](float m, float rz, float d2) { return (rz > 0.f && d2 < 100.f) ? m : 0.f; };  // the neighbour is above: this lane's term
     const auto theirs_of = [](float m, float rz, float d2) { return (rz < 0.f && d2 < 100.f) ? m : 0.f; }; // below: the neighbour's (0 when dz == 0)
+    // The tile reads run ONE PASS AHEAD of the arithmetic (round 5): the `asm volatile` below ends a scheduling region, and the
+    // compiler issued a pass's three ds_read2_b32 and waited for them on the spot.  Reads return in order; the wait for a pass's
+    // operands now falls a whole pass after their issue (inside the noise on its own: 22.18 against 22.26 us per step; together
+    // with regions of four passes, MRS_DW_REGION, -0.25 us).
+    const auto rd = [&](int k, f2 &x, f2 &y, f2 &z) { x = f2{t[k], t[k + 1]}; y = f2{t[128 + k], t[128 + k + 1]}; z = f2{tz[k], tz[k + 1]}; };
+    f2 nx, ny, nz;
     {   // k = 31, and the antipode k = 32, which both ends evaluate (each keeps its own term)
-        f2 rx, ry, rz;
-        tile64_rel2(t, 31, mx, my, mz, rx, ry, rz);
+        f2 cx, cy, cz;
+        rd(31, cx, cy, cz);
+        rd(29, nx, ny, nz);
+        const f2 rx = pk_sub(cx, mx), ry = pk_sub(cy, my), rz = pk_sub(cz, mz);
         const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
         const f2 m = mag2(d2, rz);
         keep = f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
@@ -736,9 +746,10 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
         const int k = 29 - 2 * j;
+        const f2 cx = nx, cy = ny, cz = nz;
+        if (j < 14) rd(k - 2, nx, ny, nz);
         hook(j);
-        f2 rx, ry, rz;
-        tile64_rel2(t, k, mx, my, mz, rx, ry, rz);
+        const f2 rx = pk_sub(cx, mx), ry = pk_sub(cy, my), rz = pk_sub(cz, mz);
         const f2 d2 = pk_fma(ry, ry, pk_mul(rx, rx));
         if (!SKIP || downwash_pass_live(d2, rz, dr)) {
             const f2 m = mag2(d2, rz);
@@ -746,7 +757,10 @@ __device__ __forceinline__ double downwash_ring64(const float *t, float mx_, flo
             trav = f32add(wave_ror1(trav), theirs_of(m.x, rz.x, d2.x)); // k
             keep = keep + f2{mine_of(m.x, rz.x, d2.x), mine_of(m.y, rz.y, d2.y)};
         } else trav = wave_ror1(wave_ror1(trav)); // two exact zeros on board: the word still travels its two lanes
-        asm volatile("" : "+v"(keep)); // formed here, not sunk to the end of the loop
+#ifndef MRS_DW_REGION
+#define MRS_DW_REGION 4 // passes per scheduling region of the pair loop (A/B): the asm statement below ends a region
+#endif
+        if (MRS_DW_REGION > 0 && (j % MRS_DW_REGION) == MRS_DW_REGION - 1) asm volatile("" : "+v"(keep)); // formed here, not sunk to the end of the loop
         if ((j & 3) == 3) { dkeep += (double)f32add(keep.x, keep.y); keep = f2{0.f, 0.f}; }
     }
     dkeep += (double)f32add(keep.x, keep.y);

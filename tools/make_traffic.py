@@ -41,7 +41,7 @@ sq = {k: float(np.mean(v)) for k, v in sq.items()}
 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines
 valu_busy = (sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (sq["SQ_BUSY_CYCLES"] / 32)
 out = {
-    "round": 4,
+    "round": 5,
     "source": "profiles/%s_* (commit %s)" % (name, commit),
     "command": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE|SQ_...} --output-format csv -- python3 bench.py "
                "--steps 300 --warmup 100 --no-cpu-baseline --no-dense-a (700 untimed roll-in steps; one pass per counter group, MRS_BENCH_PREWARM_S=0)",
