@@ -84,7 +84,7 @@ typedef struct MrsParams {
     /* 1: the attitude controller rebuilds its rotation matrix from the FLOAT32-rounded Euler angles exactly as
      * from_euler(get_ori()) does (Object.py:97 -> QuadControl.py:99); 0 (default): from the unrounded angles of the same
      * float32 quaternion read-back -- they differ by <= 2^-24 relative per angle, the reference's own read-back noise
-     * (deviation 7); saves ~130 float64 instructions per agent-step. */
+     * (docs/experiments.md section 4, deviation 7); saves ~130 float64 instructions per agent-step. */
     int32_t round_euler_readback;
     /* 1 (default): quad-quad contact -- every quadcopter a sphere of coll_radius; a pair within contact_threshold gets,
      * per body, half of the normal velocity change that closes the gap this step / pushes the overlap out with erp (one

@@ -188,7 +188,7 @@ __device__ __forceinline__ float wave_ror1(float v) { return __int_as_float(__bu
 // env reads the same j -- puts agents j and j+1 into a register pair, the differences and the squared distance of
 // both come from five packed instructions, and each verdict lands at a compile-time bit position (one select and one
 // OR; the row's own bit is cleared once at the end).  Was: one float4 read, six scalar operations, two compares and a
-// 64-bit variable shift per agent -- 13 vector instructions per pair against 6 (N = 256: 68 -> see DESIGN.md section 6).
+// 64-bit variable shift per agent -- 13 vector instructions per pair against 6 (N = 256: 68 -> see docs/experiments.md section 6).
 __device__ __forceinline__ bool adjacency_row(const StepArgs &A, float thr_s, const float *tx, const float *ty, const float *tz, int i, float4 me, uint64_t *row,
                                               unsigned long long *hrow)
 {

@@ -22,16 +22,23 @@ def test_fma_division_by_ctrl_dt_is_correctly_rounded(dt):
         q1 = (q0.astype(np.float64) + (x64 - d64 * q0.astype(np.float64)) * r64).astype(np.float32)
     ok = np.isfinite(want) & (np.abs(want) > 1e-30)
     assert np.array_equal(q1[ok], want[ok])
-    # outside the refinement's domain the kernel takes the division proper: +-inf, quotients that overflow
-    # (near FLT_MAX), are zero or subnormal.  The guard is "the first quotient q0 is a normal number" (v_cmp_class_f32); inside
-    # it the refinement must be exact -- checked above for |want| > 1e-30 -- and everything outside it must be caught.
-    big = np.array([np.inf, -np.inf, 3.4e38, -3.4e38, 3.3e36, 2.9e36, 1e-40, -1e-40, 1.3e-40, 0.0], np.float32)
+    # outside the refinement's domain (round 5, MRS_DIV_GUARD 2: a select, no branch) the kernel keeps the first quotient q0 wherever q0
+    # is not a normal number (v_cmp_class_f32): q0 IS the division's result for +-inf, for an overflowing product and for +-0; a
+    # subnormal q0 may be one subnormal ulp (1.4e-45) off the correctly rounded quotient.  Inside the guard the refinement must be
+    # exact -- checked above for |want| > 1e-30 -- and everything outside it must be caught.
+    big = np.array([np.inf, -np.inf, 3.4e38, -3.4e38, 3.3e36, 2.9e36, 1e-40, -1e-40, 1.3e-40, 3e-43, 0.0, -0.0], np.float32)
     with np.errstate(all="ignore"):
         q0b = (big.astype(np.float64) * r64).astype(np.float32)
         guarded = ~(np.isfinite(q0b) & (np.abs(q0b) >= np.finfo(np.float32).tiny))
         wantb = (big.astype(np.float64) / d64).astype(np.float32)
         q1b = (q0b.astype(np.float64) + (big.astype(np.float64) - d64 * q0b.astype(np.float64)) * r64).astype(np.float32)
-    assert guarded[0] and guarded[1] and guarded[-1]                        # inf, -inf, 0
+    assert guarded[0] and guarded[1] and guarded[-1] and guarded[-2]        # inf, -inf, 0, -0
     assert np.isnan(q1b[0]) and np.isinf(wantb[0])                          # what the unguarded form would have returned
     un = ~guarded
     assert np.array_equal(q1b[un], wantb[un])
+    got = np.where(guarded, q0b, q1b)                                       # the kernel's select
+    sub = guarded & np.isfinite(q0b) & (q0b != 0)
+    exact = guarded & ~sub
+    assert np.array_equal(got[exact], wantb[exact]) and np.array_equal(np.signbit(got[exact]), np.signbit(wantb[exact]))
+    ulp = np.abs(got[sub].view(np.int32).astype(np.int64) - wantb[sub].view(np.int32).astype(np.int64))
+    assert sub.any() and ulp.max() <= 1

@@ -712,7 +712,7 @@ def test_handle_on_a_device_that_is_not_the_current_one():
 
 def test_round_euler_readback_kwarg_reaches_the_kernel():
     """MRS(..., ROUND_EULER_READBACK=True) selects the attitude controller's literal float32 rounding of the Euler
-    read-back (include/mrs_hip.h, DESIGN.md section 4 deviation 7): the flag arrives in the shard's parameters, and one
+    read-back (include/mrs_hip.h; docs/experiments.md section 4 deviation 7): the flag arrives in the shard's parameters, and one
     step of the two forms differs by what that rounding is worth -- more than nothing, less than 1e-6 rad/s."""
     import mrsgym_amd
     E, N = 3, 12

@@ -22,7 +22,7 @@ controller memory) every step.  Per step and body, |delta| relative above magnit
     5e-5, and one stopping decision that did fall a pair of sweeps apart, 1.85e-4: profiles/r04_teacher_forced.txt);
   * adjacency rows and the observation slice bit-exact every step;
 and the run must have visited touchdown, rest, tumbling on the ground and pair contact.
-Per-phase error quantiles of the same runs: tools/teacher_probe.py -> profiles/r04_teacher_forced.txt.
+Per-phase error quantiles of the same runs: tools/teacher_probe.py -> profiles/r05_teacher_forced.txt.
 """
 import numpy as np
 import pytest
