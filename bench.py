@@ -212,8 +212,16 @@ def main():
     # spans of 10 the average came out 0.3 - 0.4 us ABOVE the wall-clock time per step of the same region -- the two records'
     # own cost lands inside the span and was divided by 10 (tools/probes/ev_span_test.sh: span 10: kernel 22.80 / step 22.46 us;
     # span 25 ... 50: 22.29 / 22.28, 22.35 / 22.50) -- and a rocprofv3 kernel trace of the same run sat 0.9 us below it.
+    # Round 5: a span's opening event is recorded AFTER the span's first launch and the span is divided by the EV_SPAN - 1 launches
+    # it brackets.  Recording it first put its host cost (12 - 18 us on an idle queue, step-by-step stamps under
+    # MRS_BENCH_DEBUG_STEPS=1) between the synchronize and the first launch of the timed region: 0.85 us per step of `value` in
+    # the 20-step form, and the first launch's own submission (9 us with the GPU idle) inside the span.  Behind a launch the record
+    # is hidden by the running kernel and its timestamp is that kernel's end.  It is recorded after the span's THIRD launch (EV_OPEN):
+    # the first record after a synchronize costs the host ~20 us, and behind one queued kernel (22 us) the GPU still ran dry for
+    # ~10 us; behind three the queue holds two kernels more.  A span brackets EV_SPAN - EV_OPEN launches.
     EV_EVERY = int(os.environ.get("MRS_BENCH_EVENT_EVERY", "50"))
-    EV_SPAN = max(1, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "50")), EV_EVERY, args.steps))
+    EV_SPAN = max(2, min(int(os.environ.get("MRS_BENCH_EVENT_SPAN", "50")), EV_EVERY, args.steps))
+    EV_OPEN = 3 if EV_SPAN >= 10 else 1
 
     def rollin(env):
         """ROLLIN untimed steps from the spawn state: the workload's steady state (a part of the swarm grounded).
@@ -244,6 +252,9 @@ def main():
         # hipEventRecord of a process runs library code that is not paged in yet
         warm_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         warm_ev[0].record()
+        for a_, b_ in ev:      # torch creates the HIP event at its first record(): here, not inside the timed steps
+            a_.record()
+            b_.record()
         for t in range(t_first, t_first + args.warmup):
             one_step(t)
         warm_ev[1].record()
@@ -254,12 +265,17 @@ def main():
             i = timed_step.i
             timed_step.i = i + 1
             j, r = divmod(i, EV_EVERY)
-            if j < len(ev) and r == 0:
-                ev[j][0].record()
+            if DBG: tt = [time.perf_counter()]
             shard_step(*a, **k)
+            if DBG: tt.append(time.perf_counter())
+            if j < len(ev) and r == EV_OPEN - 1:
+                ev[j][0].record()
+            if DBG: tt.append(time.perf_counter())
             if j < len(ev) and r == EV_SPAN - 1:
                 ev[j][1].record()
+            if DBG: tt.append(time.perf_counter()); dbg.append(tt)
         timed_step.i = 0
+        DBG = bool(os.environ.get("MRS_BENCH_DEBUG_STEPS")); dbg = []
         if not os.environ.get("MRS_BENCH_DEBUG_NOSYNC"):   # diagnostic only: the contract requires this synchronize
             torch.cuda.synchronize()
         if world > 1:
@@ -267,9 +283,15 @@ def main():
             torch.cuda.synchronize()
         env.shard.step_ptr = timed_step
         t0 = time.perf_counter()
+        tp, host_max = t0, 0.0
         for t in range(t_first + args.warmup, t_first + total):
             one_step(t)
-        host_elapsed = time.perf_counter() - t0     # launch loop only: equals `elapsed` when the host is the limit
+            tn = time.perf_counter()
+            if tn - tp > host_max:                  # the longest single pass of the launch loop: a host stall shows here
+                host_max, timed_region.host_max_at = tn - tp, t - t_first - args.warmup
+            tp = tn
+        host_elapsed = tp - t0                      # launch loop only: equals `elapsed` when the host is the limit
+        timed_region.host_max = host_max
         if with_gather:
             gather.wait()
         torch.cuda.synchronize()
@@ -279,9 +301,13 @@ def main():
         elapsed = time.perf_counter() - t0
         env.shard.step_ptr = shard_step
         env.check_errors()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / EV_SPAN
+        if DBG:
+            print("t0->", " | ".join("%.1f %.1f %.1f %.1f" % tuple((x - t0) * 1e6 for x in tt) for tt in dbg[:3] + dbg[-2:]), "end %.1f" % (elapsed * 1e6), file=sys.stderr)
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (EV_SPAN - EV_OPEN)
+        if args.steps < 2:          # no second launch to close a span with: the synchronized wall time of the one step
+            kernel_ms = elapsed * 1e3
         if os.environ.get("MRS_BENCH_DEBUG_SPANS"):   # diagnostic: the sampled spans in order (us per launch)
-            print("spans:", " ".join("%.1f" % (a.elapsed_time(b) / EV_SPAN * 1e3) for a, b in ev), file=sys.stderr, flush=True)
+            print("spans:", " ".join("%.1f" % (a.elapsed_time(b) / (EV_SPAN - EV_OPEN) * 1e3) for a, b in ev), file=sys.stderr, flush=True)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -311,6 +337,7 @@ def main():
     if world == 1:
         # `value`: the step itself -- one GPU, nothing to exchange
         elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, False, read_A=args.dense_a)
+        host_max, host_max_at = timed_region.host_max, timed_region.host_max_at
         if not args.no_dense_a and not args.dense_a:
             # the reference's return format: float32 0/1 (E,K+1,N,N) adjacency materialised every step (a second launch)
             del env
@@ -388,6 +415,7 @@ def main():
     else:
         # `value`: BASELINE config 5 / north_star -- every step followed by the RCCL all-gather of the joint observation
         elapsed, host_elapsed, kernel_ms = timed_region(env, args.rollin, True)
+        host_max, host_max_at = timed_region.host_max, timed_region.host_max_at
         # the kernel's own duration for the roofline object comes from the region without the gather: with it the event
         # spans on the step stream include the back-pressure waits for the side stream
         n_elapsed, _, kernel_ms = timed_region(env, args.rollin + total, False)
@@ -450,7 +478,7 @@ def main():
         "metric": "agent-steps/sec (whole node) at N_AGENTS=64 x4096 envs", "value": value, "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rollin_steps": args.rollin,
         "grounded_fraction_after_rollin": float(grounded), "ms_per_step": elapsed / args.steps * 1e3,
-        "host_ms_per_step": host_elapsed / args.steps * 1e3,
+        "host_ms_per_step": host_elapsed / args.steps * 1e3, "host_ms_longest_step": host_max * 1e3, "host_longest_step_index": host_max_at,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "precision": "float64 rigid-body state, controller and force assembly (as Bullet / numpy in the reference); float32 where the "
                      "reference is float32 (read-backs, downwash pair terms, adjacency distances) and, the build's own choice, in the "
