@@ -1523,6 +1523,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
                 write_obs(A, wb.obs + la * (unsigned)A.D, p, q, v, w);
             }
         };
+        // (Round 5 experiment, removed: at N = 64 every wave solving its own listed bodies in their own lanes through the stash -- no
+        // list, no barrier, no wave waiting for another one's bodies; bit-identical results.  24.9 against 22.3 us per step in a
+        // same-process A/B: 2.5 solving waves per workgroup instead of one, and the vector slots they take are not idle ones.)
         // (Round 3 experiment, removed: the lanes that are not listed for the solve -- 19 out of 20 -- finishing their step
         // between the two barriers, under the solver wave's serial chain, and the listed ones behind it.  25.9 against 23.4 us
         // per step: two exec-masked passes over the 13 state stores write partial cache lines instead of whole ones.)

@@ -44,29 +44,34 @@ def line(name, us, nbytes, note=""):
     print("%-44s %9.1f us per call  %8.2f MB algorithmic  %7.1f GB/s  %s" % (name, us, nbytes / 1e6, nbytes / us / 1e3, note), flush=True)
 
 
-E, N = 4096, 64
-sh, obs = swarm(E, N)
-R = 8
-dirs = np.random.default_rng(0).normal(size=(R, 3)).astype(np.float32); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-off = np.array([0, 0, -0.1], np.float32)
-us = timeit(lambda: sh.raycast(off, dirs, body=True, RANGE=5.0), 20)
-line("mrs_raycast  N=64 x4096, 8 rays per agent", us, E * N * (28 + R * 32), "(each ray against 64 cylinders + the ground box)")
-us = timeit(lambda: sh.proximity(points=True), 5)
-line("mrs_proximity N=64 x4096, with points", us, E * N * (28 + (N + 1) * 28), "(4032 GJK pairs per env, float64)")
-us = timeit(lambda: sh.proximity(max_dist=0.02, points=True), 10)
-line("mrs_proximity N=64 x4096, max_dist 0.02, points", us, E * N * (28 + (N + 1) * 28), "(what collisions / get_contact_points ask for)")
-us = timeit(lambda: sh.proximity(max_dist=0.5), 10)
-line("mrs_proximity N=64 x4096, max_dist 0.5", us, E * N * (28 + (N + 1) * 4), "(bounding-sphere cull in front of GJK)")
-act = torch.zeros(E, N, 3, device="cuda:0")
-h = sh.h
-us = timeit(lambda: native._check(sh.L.mrs_reynolds(h, native._ptr(obs), 6, native._ptr(act), native._stream(sh.device)), "mrs_reynolds"), 50)
-line("mrs_reynolds N=64 x4096 (K = 1)", us, E * N * (24 + 12))
-X = obs.reshape(1, E, N, 6).expand(4, E, N, 6).contiguous()
-us = timeit(lambda: native.flock_metrics(X), 20)
-line("mrs_flock_metrics 16384 frames of N=64", us, 4 * E * N * 24 + 4 * E * (N + 4) * 4)
-E2, N2 = 4096, 12
-sh2 = mrsgym_amd.SwarmShard(E2, N2, "cuda:0")
-lo = (native.C.c_float * 3)(0, 0, -1.57); hi = (native.C.c_float * 3)(0, 0, 1.57)
-b = sh2._buffers()
-us = timeit(lambda: native._check(sh2.L.mrs_spawn(sh2.h, native.C.byref(b), 1234, 0, 0.3, lo, hi, 200, None, native._stream(sh2.device)), "mrs_spawn"), 20)
-line("mrs_spawn N=12 x4096 (default distribution)", us, E2 * N2 * 13 * 4, "(rejection rounds in LDS)")
+def main():
+    E, N = 4096, 64
+    sh, obs = swarm(E, N)
+    R = 8
+    dirs = np.random.default_rng(0).normal(size=(R, 3)).astype(np.float32); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    off = np.array([0, 0, -0.1], np.float32)
+    us = timeit(lambda: sh.raycast(off, dirs, body=True, RANGE=5.0), 20)
+    line("mrs_raycast  N=64 x4096, 8 rays per agent", us, E * N * (28 + R * 32), "(each ray against 64 cylinders + the ground box)")
+    us = timeit(lambda: sh.proximity(points=True), 5)
+    line("mrs_proximity N=64 x4096, with points", us, E * N * (28 + (N + 1) * 28), "(4032 GJK pairs per env, float64)")
+    us = timeit(lambda: sh.proximity(max_dist=0.02, points=True), 10)
+    line("mrs_proximity N=64 x4096, max_dist 0.02, points", us, E * N * (28 + (N + 1) * 28), "(what collisions / get_contact_points ask for)")
+    us = timeit(lambda: sh.proximity(max_dist=0.5), 10)
+    line("mrs_proximity N=64 x4096, max_dist 0.5", us, E * N * (28 + (N + 1) * 4), "(bounding-sphere cull in front of GJK)")
+    act = torch.zeros(E, N, 3, device="cuda:0")
+    h = sh.h
+    us = timeit(lambda: native._check(sh.L.mrs_reynolds(h, native._ptr(obs), 6, native._ptr(act), native._stream(sh.device)), "mrs_reynolds"), 50)
+    line("mrs_reynolds N=64 x4096 (K = 1)", us, E * N * (24 + 12))
+    X = obs.reshape(1, E, N, 6).expand(4, E, N, 6).contiguous()
+    us = timeit(lambda: native.flock_metrics(X), 20)
+    line("mrs_flock_metrics 16384 frames of N=64", us, 4 * E * N * 24 + 4 * E * (N + 4) * 4)
+    E2, N2 = 4096, 12
+    sh2 = mrsgym_amd.SwarmShard(E2, N2, "cuda:0")
+    lo = (native.C.c_float * 3)(0, 0, -1.57); hi = (native.C.c_float * 3)(0, 0, 1.57)
+    b = sh2._buffers()
+    us = timeit(lambda: native._check(sh2.L.mrs_spawn(sh2.h, native.C.byref(b), 1234, 0, 0.3, lo, hi, 200, None, native._stream(sh2.device)), "mrs_spawn"), 20)
+    line("mrs_spawn N=12 x4096 (default distribution)", us, E2 * N2 * 13 * 4, "(rejection rounds in LDS)")
+
+
+if __name__ == "__main__":
+    main()
