@@ -664,6 +664,9 @@ MRS_DEV void integrate_velocity(const MrsParams &P, const Recips &K, const M3 &R
 // Geometry, gaps and the rhs are formed in float64; the sweeps run in float32 on velocity CHANGES (dv, dw), which the
 // caller adds to the float64 state.  Impulses are ~m g dt = 2.6e-3 N s, so float32 carries them to ~1e-10; the stated
 // tolerance against the float64 oracle is 1e-4 per step, 1e-3 over a touchdown.
+#ifndef MRS_SKIP_IDLE_POINTS
+#define MRS_SKIP_IDLE_POINTS 1
+#endif
 #ifndef MRS_CONTACT_TOL
 #define MRS_CONTACT_TOL 1e-7f
 #endif
@@ -846,9 +849,21 @@ MRS_DEV void contact_solve_rows(const MrsParams &P, const Recips &K, double pz, 
     // and the wave leaves the loop when its last lane has (at most solver_iters sweeps, like the oracle).
     // Convergence is looked at on every second sweep only (the bookkeeping is ~8 % of a sweep).
     const S tol = (S)MRS_CONTACT_TOL * rest + (S)1e-30f;
+    // a rim point that is within the threshold for NO body of the wave is skipped: its rows are exact no-ops (zero effective masses,
+    // impulses stay 0), so this changes no result and no body's result depends on its wave-mates -- only the time does
+    bool pt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#if defined(MRS_HOST_CHECK) || !MRS_SKIP_IDLE_POINTS
+        pt[k] = true;
+#else
+        pt[k] = __builtin_amdgcn_ballot_w64(Kn[k] != (S)0) != 0;
+#endif
+    }
     auto sweep = [&](auto track, S &moved) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if (!pt[k]) continue;
             const S rx = r[k].x, ry = r[k].y, rz = r[k].z;
             { // normal: u = (ry, -rx, 0)
                 const S dvn = fm(-dwxy.y, rx, fm(dwxy.x, ry, dvz));

@@ -2061,9 +2061,11 @@ extern "C" int mrs_create(const MrsParams *params, int n_envs, int n_agents, int
         int ncu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        h->sblock = 64;
-        for (int sb = 256; sb >= 128; sb >>= 1)
-            if ((n_envs + sb / 64 - 1) / (sb / 64) >= ncu) { h->sblock = sb; break; }
+        // Round 5, by resident waves per SIMD (one env = one wave): up to one 64 threads, up to two 128, more 256 -- us per step
+        // (tools/steady_bench.py, bench action type) at 1024 envs: 64: 14.95, 128: 15.37, 256: 15.09; 2048 envs: 17.35, 16.35, 17.07;
+        // 3072 envs: 20.91, 21.31, 18.99; BASELINE config 2 (set_speeds, 1024 envs, no A): 13.60, 14.21, 14.15.  (Before: the largest
+        // size that still gave every CU a workgroup, i.e. 256 from 1024 envs on.)
+        h->sblock = n_envs <= 4 * ncu ? 64 : (n_envs <= 8 * ncu ? 128 : 256);
     }
     if (const char *sb = getenv("MRS_STEP_BLOCK")) {
         const int v = atoi(sb);
