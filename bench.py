@@ -494,7 +494,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_step<set_target_vel>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": algo_bytes_launch,
-                     "limiter": "the waves' dependency chains at 4 waves per SIMD (a lone wave needs 12 us for the step, four share a SIMD in 18; the contact hand-off is 4 us of it) -- not HBM bandwidth, never MFMA: see DESIGN.md section 3", "valu_busy": valu_busy,
+                     "limiter": "the instruction stream itself: ~2000 vector instructions per wave, a third of them float64, at 77 % VALU occupancy with 4 waves per SIMD (a lone wave needs 12 us for the step; the many-round asymptote is 21 us per 4096 envs) -- not HBM bandwidth, never MFMA: see DESIGN.md section 3", "valu_busy": valu_busy,
                      "counters_from": prof_src},
     }
     out.update(extra)
