@@ -318,7 +318,11 @@ __device__ __forceinline__ void tile64_rel2z(const float *t, PZ tz, int k, f2 mx
 //   want_hit: also the smallest squared distance this lane has seen (quad-quad contact range: one v_min3_f32 per two pairs;
 //   round 2 built a bit per pair, three instructions each, for an event that concerns 0.1-0.3 % of the envs)
 // (Round 2 experiment, removed: evaluating the NEXT step's downwash in this loop and carrying the force to the next launch:
-// +1.2 us per step, the work moves from the start of the kernel, where issue slots are idle, to its end, where none are.)
+// +1.2 us per step, the work moves from the start of the kernel, where issue slots are idle, to its end, where none are.
+// Round 5, built again on the present kernel -- the pair term riding in this loop on the shared differences and dxy^2, the sum and a
+// 64-bit signature of the position in a 16-byte record per agent, taken by the next step when all 64 signatures of the env match;
+// bit-identical results, no scratch, the start's loop, tile and 96 LDS reads gone for 99.9 % of the envs: +4.0 us per step.  The
+// tail is what the launch's latest workgroups run ALONE, behind their contact solve; an instruction there costs three of the start's.)
 __device__ __forceinline__ void adj64_pass(const float *t, float mex, float mey, float mez, float thr_s, bool rows, bool want_hit, int lane,
                                            uint64_t &row, float &dmin)
 {
