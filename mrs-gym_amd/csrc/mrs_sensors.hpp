@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_raycast(const RayArgs S)
     extern __shared__ double lc[]; // [N][6] centre, axis; then [N][12] floats: the casting agent's float32 read-back (matrix, position);
                                    // then [3][NP] floats: the centres once more, float32, one plane per coordinate (the cull below)
     float *rb = reinterpret_cast<float *>(lc + 6 * S.N);
-    const int NP = (S.N + 1) & ~1;
+    const int NP = (S.N + 63) & ~63; // whole blocks of 64: the pad slots hold a centre nothing comes near
     float *cf = rb + 12 * S.N;
     const int e = blockIdx.x;
     const size_t a0 = (size_t)e * S.N, T = S.T;
@@ -191,27 +191,37 @@ __global__ __launch_bounds__(256) void k_raycast(const RayArgs S)
         // a segment it calls a miss is a miss in float64 as well, the survivors are a few more than before, and the exact float64 test
         // that decides is untouched: same hits.  With the divisions and the root of the exact tests as reciprocals with two Newton steps
         // (g_rcp, g_rsqrt): 190 -> 164 us per call at N = 64 x 4096, 8 rays (same box).
+        // Then: ONE sign per cylinder -- the smallest of three slacks of the line's distance and closest-point parameter, a superset of the
+        // segment test -- and the candidate mask shifted together two bits per pass: 165 -> 126 us.  (Measured and not kept: the
+        // survivors of a round of 256 rays compacted into an LDS list and tested densely, nearest hit by 64-bit atomic minima -- same hits,
+        // 182 us: the exact tests are not where the time is, the cull's 64 tests per ray are.)
         typedef float F2 __attribute__((ext_vector_type(2)));
         const float ox = st[0], oy = st[1], oz = st[2], dxf = (float)d.x, dyf = (float)d.y, dzf = (float)d.z;
         const float ddf = dxf * dxf + dyf * dyf + dzf * dzf;
         const float rho2f = (float)((S.rc * S.rc + S.hl * S.hl) * 1.02), kap = 4e-6f;
+        // candidate <=> the LINE comes within rho of the centre, at a parameter within [-rho/|d|, 1 + rho/|d|] (a superset of the
+        // segment's bounding-sphere test: one sign to look at per cylinder instead of a three-way case)
+        const float sd = sqrtf(rho2f * ddf) * 1.01f + 1e-6f * ddf, sdd = ddf + sd, kdd = kap * ddf; // (margins: b carries ~1e-6 of |oc| |d|)
         for (int j0 = 0; j0 < S.N; j0 += 64) {
-            unsigned long long cand = 0;
-            const int jn = min(64, S.N - j0);
-            for (int jj = 0; jj < jn; jj += 2) {
-                const int j = j0 + jj;
-                const F2 cx = *reinterpret_cast<const F2 *>(cf + j), cy = *reinterpret_cast<const F2 *>(cf + NP + j), cz = *reinterpret_cast<const F2 *>(cf + 2 * NP + j);
-                const F2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-                const F2 q = ocx * ocx + ocy * ocy + ocz * ocz, b = ocx * dxf + ocy * dyf + ocz * dzf;
-                const F2 c0 = q - rho2f;
-                // squared distance from the centre to the segment against rho^2 (times dd in the third case): closest point at t = 0, 1 or -b / dd
-                const F2 m0 = c0 - kap * q, m1 = (c0 + 2.f * b + ddf) - kap * (q + ddf), m2 = (c0 * ddf - b * b) - kap * (q * ddf);
+            unsigned wlo = 0, whi = 0;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool miss = (b[u] >= 0.f) ? (m0[u] > 0.f) : ((-b[u] >= ddf) ? (m1[u] > 0.f) : (m2[u] > 0.f));
-                    cand |= (miss || jj + u >= jn) ? 0ull : (1ull << (jj + u));
+            for (int h = 0; h < 2; ++h) {
+                unsigned wbits = 0;
+#pragma unroll 8
+                for (int jj = 30; jj >= 0; jj -= 2) { // descending: the word is shifted up two bits per pass
+                    const int j = j0 + 32 * h + jj;
+                    const F2 cx = *reinterpret_cast<const F2 *>(cf + j), cy = *reinterpret_cast<const F2 *>(cf + NP + j), cz = *reinterpret_cast<const F2 *>(cf + 2 * NP + j);
+                    const F2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+                    const F2 q = ocx * ocx + ocy * ocy + ocz * ocz, b = ocx * dxf + ocy * dyf + ocz * dzf;
+                    // dd (q - rho^2) - b^2 <= margin, b <= sd, -b <= dd + sd: the smallest of the three slacks is >= 0
+                    const F2 s0 = (b * b - (q - rho2f) * ddf) + q * kdd, s1 = sd - b, s2 = b + sdd;
+                    const F2 sl = __builtin_elementwise_min(__builtin_elementwise_min(s0, s1), s2);
+                    // (a NaN slack -- a non-finite centre -- compares false with "< 0": the cylinder goes to the exact test, as before)
+                    wbits = (wbits << 2) | (sl.y < 0.f ? 0u : 2u) | (sl.x < 0.f ? 0u : 1u);
                 }
+                if (h == 0) wlo = wbits; else whi = wbits;
             }
+            unsigned long long cand = ((unsigned long long)whi << 32) | wlo;
             while (cand) {
                 const int j = j0 + __builtin_ctzll(cand);
                 cand &= cand - 1;
@@ -429,7 +439,11 @@ struct ProxArgs {
 // other 63 lanes had nothing to do -- with a contact-range cull (collisions, get_contact_points: a handful of survivors per
 // env) that was most of the 646 us the call took at N = 64 x 4096 (profiles/r03_sensor_bench.txt).
 constexpr int PROX_CHUNK = 1024;
-__global__ __launch_bounds__(256) void k_proximity(const ProxArgs S)
+// WGS = workgroups per CU the register budget is cut for (round 5, N = 64 x 4096, us per call with WGS = 2 / 3): every pair through GJK,
+// with points 759 / 708, without 725 / 613, max_dist 0.5: 325 / 298 -- but max_dist 0.02 with points, where nearly every pair is culled and
+// the call is its 484 MB of stores: 217 / 283.  mrs_proximity takes 2 for contact-range queries and 3 otherwise.
+template <int WGS>
+__global__ __launch_bounds__(256, WGS) void k_proximity(const ProxArgs S)
 {
     extern __shared__ double lc[];
     __shared__ int s_n;
@@ -589,7 +603,7 @@ extern "C" int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offse
     S.rc = h->P.coll_radius; S.hl = h->P.coll_half_len; S.ground_z = h->P.ground_z; S.T = (size_t)h->E * h->N;
     // 108 bytes of LDS per agent: above 64 KB (N >= 607; mrs_create takes N up to 1024 = 108 KB of the CU's 160) the launch needs the
     // function attribute raised, once per handle = per device (the guard that stood here refused what used to run)
-    const size_t lds = (size_t)h->N * (6 * sizeof(double) + 12 * sizeof(float)) + (size_t)((h->N + 1) & ~1) * 3 * sizeof(float);
+    const size_t lds = (size_t)h->N * (6 * sizeof(double) + 12 * sizeof(float)) + (size_t)((h->N + 63) & ~63) * 3 * sizeof(float);
     if (lds > 64 * 1024 && !h->raycast_big_lds) {
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&mrs_sense::k_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return hipfail(ea, "mrs_raycast: raising the LDS limit");
@@ -608,7 +622,9 @@ extern "C" int mrs_proximity(MrsHandle *h, const MrsBuffers *b, double max_dist,
     memset(&S, 0, sizeof(S));
     S.b = *b; S.dist = dist; S.p_self = p_self; S.p_other = p_other; S.E = h->E; S.N = h->N;
     S.rc = h->P.coll_radius; S.hl = h->P.coll_half_len; S.ground_z = h->P.ground_z; S.max_dist = max_dist; S.T = (size_t)h->E * h->N;
-    hipLaunchKernelGGL(mrs_sense::k_proximity, dim3(h->E), dim3(256), (size_t)h->N * 6 * sizeof(double), (hipStream_t)stream, S);
+    const double bound = std::sqrt(S.rc * S.rc + S.hl * S.hl);
+    if (max_dist <= 4 * bound) hipLaunchKernelGGL(mrs_sense::k_proximity<2>, dim3(h->E), dim3(256), (size_t)h->N * 6 * sizeof(double), (hipStream_t)stream, S);
+    else hipLaunchKernelGGL(mrs_sense::k_proximity<3>, dim3(h->E), dim3(256), (size_t)h->N * 6 * sizeof(double), (hipStream_t)stream, S);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hipfail(e, "mrs_proximity launch");
 }
