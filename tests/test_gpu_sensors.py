@@ -56,6 +56,36 @@ def test_raycast_matches_oracle(E, N):
     assert (out["object"][..., 0] >= 0).all()
 
 
+@pytest.mark.parametrize("centre", [(0.0, 0.0), (13.0, -13.0), (-14.2, 14.2)])
+def test_raycast_aimed_rays_survive_the_float32_cull(centre):
+    """Round 5: the bounding-sphere cull in front of the exact ray / cylinder test runs in float32 with margins (mrs_sensors.hpp).
+    Rays aimed from agent 0 at the centre of every other agent -- and the same rays shifted sideways by most of the collision
+    radius -- cannot be lost to it wherever the swarm sits on the 30 m ground box: hit object and distance as the oracle has them."""
+    rng = np.random.default_rng(int(abs(centre[0]) * 10) + 3)
+    E, N = 12, 9
+    pos, quat = _scene(rng, E, N, spread=1.2, z=(0.8, 2.5))
+    pos[..., 0] += centre[0]; pos[..., 1] += centre[1]
+    sh = _shard(pos, quat)
+    checked = 0
+    for e in range(E):
+        d = pos[e, 1:] - pos[e, 0]
+        dist = np.linalg.norm(d, axis=1)
+        dirs = (d / dist[:, None]).astype(np.float32)
+        for shift in (0.0, 0.045):
+            side = np.cross(dirs, [0, 0, 1.0]); side /= np.maximum(np.linalg.norm(side, axis=1, keepdims=True), 1e-9)
+            off = (shift * side[0]).astype(np.float32)                          # one offset per call (Object.raycast: offset is shared)
+            out = sh.raycast(off, dirs, body=False, RANGE=float(dist.max() + 1.0))
+            obj = out["object"][e, 0].cpu().numpy(); dd = out["dist"][e, 0].cpu().numpy()
+            want = oracle.raycast(pos[e], quat[e], 0, off, dirs.copy(), body=False, RANGE=float(dist.max() + 1.0))
+            if shift == 0.0:
+                assert (want["object"] >= 0).all() and (want["object"] != 0).all()   # aimed at a centre: something is hit on the way
+            same = obj == want["object"]
+            assert same.all(), (e, shift, obj, want["object"])
+            np.testing.assert_allclose(dd, want["dist"], atol=2e-5)
+            checked += len(obj)
+    assert checked == E * 2 * (N - 1)
+
+
 @pytest.mark.parametrize("E,N", [(4, 6), (2, 64), (1, 1)])
 def test_proximity_matches_oracle(E, N):
     rng = np.random.default_rng(7 + N)
