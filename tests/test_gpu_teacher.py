@@ -68,6 +68,26 @@ def test_teacher_forced_1000_steps_on_the_benchmarked_workload(cfg):
         assert v["pair"] > 0, v
 
 
+def test_closed_forms_for_flat_bodies_against_the_rows_themselves():
+    """the closed forms for flat bodies (mrs_device.hpp contact_at_rest) live in the kernel AND in the oracle, so parity at
+    equal settings does not check them.  Here the kernel keeps them (rest_shortcut = 1) and the oracle sends every body through the
+    rows (rest_shortcut = 0), both with 50 sweeps, teacher-forced on C2 -- the workload that ends with nearly every body lying on the
+    ground.  What separates the two is the flatness bound: a body tilted by up to MRS_FLAT_EPS = 1e-6 rad is treated as level, its
+    rim points' gaps differ by up to 1.2e-7 m, the rows answer that with up to 1.2e-7 m / dt / lever = 1e-4 rad/s of angular
+    velocity and the closed form with none.  Measured (600 steps x 16 envs, 223 k resting body-steps): median 4e-5, worst 9.6e-5."""
+    import mrsgym_amd
+    prm = mrsgym_amd.default_params()
+    prm.solver_iters, prm.rest_shortcut = 50, 1
+    r = ut.run(torch, mrsgym_amd, "C2", E=16, steps=600, params=prm, oracle_params=dict(rest_shortcut=0), unconstrained=True)
+    assert r["adj_bad"] == 0
+    x, v = r["err"]["rest"], r["vunc"]["rest"]
+    assert x.size > 100000 and r["visited"]["rest"] > 100000          # the closed forms did carry the run
+    ordinary = v < 5.0
+    assert x[ordinary].max() <= 1.5e-4, (float(x[ordinary].max()), ut.quantiles(x[ordinary]))
+    assert np.median(x[ordinary]) <= 8e-5
+    assert r["err"]["free"].max() <= TOL_FREE
+
+
 @pytest.mark.parametrize("cfg,E,steps", [("X12", 64, 400), ("X100", 12, 300), ("X192", 8, 300)])
 def test_teacher_forced_other_action_types_and_swarm_sizes(cfg, E, steps):
     """The same per-step comparison for the ACTION_TYPEs BASELINE's configs leave out (set_target_accel, set_target_ori) and the

@@ -62,7 +62,8 @@ def classify(pre, P, N):
     return ph
 
 
-def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None, unconstrained=False):
+def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None, nthreads=8, progress=None, dump=None, unconstrained=False,
+        oracle_params=None):
     """Returns dict: err[phase] = array of per-body per-step errors (max over the 13 state words, relative above
     magnitude 1; abs_err[phase]: the same words' largest ABSOLUTE difference), visited counters, adjacency mismatches (must be 0).  unconstrained=True: the oracle takes every step a
     second time with both contact models off, and vunc[phase] holds, aligned with err[phase], the largest velocity word
@@ -79,6 +80,8 @@ def run(torch, mrsgym_amd, cfg, E, steps, seed=0, check_adj_every=1, params=None
     sw = oracle.OracleSwarm(E, N, nthreads=nthreads)
     for k in ("solver_iters", "enable_contact", "pair_contact"):
         setattr(sw.p, k, int(getattr(P, k)))
+    for k, v in (oracle_params or {}).items():                  # the oracle at OTHER settings than the kernel (e.g. rest_shortcut = 0)
+        setattr(sw.p, k, v)
     acts = ActionStream(atype, E, N, pos, seed=1000 + seed)      # coherent=False: independent per-agent targets
     obs = torch.zeros(E, N, sh.D, device="cuda:0")
     adj = torch.zeros(E, N, sh.W, dtype=torch.int64, device="cuda:0") if R is not None else None
