@@ -231,7 +231,9 @@ int mrs_raycast(MrsHandle *h, const MrsBuffers *b, const float *offset, const fl
  * the same env (0 on the diagonal, 0 when the hulls overlap), column N = the ground (signed: negative when sunk in);
  * +inf where the bodies are further apart than max_dist (the reference returns an empty result there, :121-122).
  * p_self / p_other (optional, (E,N,N+1,3) float32): "closest pos self" / "closest pos other" in world coordinates.
- * collision() (:136-137), get_contact_points (:100-116) and get_closest_objects (:140-147) are thresholds on this. */
+ * collision() (:136-137), get_contact_points (:100-116) and get_closest_objects (:140-147) are thresholds on this.
+ * Accuracy: float64 GJK stopped at a relative gap of 1e-9 (the outputs are float32: half an ulp is 6e-8 relative); tested against
+ * the oracle's 1e-14 iteration at 2e-6 absolute. */
 int mrs_proximity(MrsHandle *h, const MrsBuffers *b, double max_dist, float *dist, float *p_self, float *p_other, void *stream);
 
 /* ---- flocking metrics of the reference's analytics: examples/simulating_data/helper/
