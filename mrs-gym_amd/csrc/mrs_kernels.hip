@@ -1544,6 +1544,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? (FUSED ? MRS_FUSED_WAVES : M
         TL(7); // pose + store
         if (MRS_P_ADJ != MRS_P_TAIL || MRS_P1_ADJ != MRS_P1_TAIL) MRS_SETPRIO(AN <= 64, MRS_P1_ADJ, MRS_P_ADJ);
         // (fetching the last phase's scalar arguments ahead of the second barrier was measured: no gain, 29.4 vs 29.6 us)
+        // (Round 5 experiment, removed: the N = 64 adjacency pass AHEAD of the hand-off, on p + dt v -- the final position of every body
+        // the contact rows do not touch -- with the rows and columns of the listed bodies put right in the tail from their final
+        // positions (one ballot per listed body); bit-identical rows, no scratch: 24.6 against 22.2 us per step.  The phases between
+        // the pair loop and the hand-off are where four waves per SIMD compete for issue slots; 300 more instructions there cost
+        // more than the tail saves.)
         // (Round 3 experiment, removed: the N = 64 adjacency pass taken out of this tail and run between the two barriers of the
         // hand-off on predicted positions -- final for every lane that is not listed -- with the listed agents' rows and columns
         // put right afterwards, and the solver waves' envs looked after by the waves next in line.  Bit-identical rows; 23.8 us
